@@ -1,0 +1,212 @@
+"""Container-only: emit tests/golden/*.npz from the UNMODIFIED reference Python (see oracle/ref_loader.py).
+
+Run:  python -B oracle/gen_goldens.py        (needs /root/reference; never runs on the GPU box)
+
+Every fixture is DATA: seeded inputs + the reference's outputs (fp32, and the same code under
+torch.set_default_dtype(float64) as accuracy truth).  The planar stage behind ``box_iou_rotated`` is the
+reference's vendored ``sphdet/iou/diff_iou_rotated.py`` (mmcv is not installable offline) — recorded in every
+file as ``planar='diff'``.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from ref_loader import load_reference  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+R = load_reference()
+IOU = {'standard': R.api.sph2pob_standard_iou, 'efficient': R.api.sph2pob_efficient_iou,
+       'legacy': R.api.sph2pob_legacy_iou}
+TRANS = {'standard': R.std.sph2pob_standard, 'efficient': R.eff.sph2pob_efficient, 'legacy': R.leg.sph2pob_legacy}
+
+
+def f64(fn, *tensors, **kw):
+    torch.set_default_dtype(torch.float64)
+    try:
+        return fn(*[t.double() for t in tensors], **kw)
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def gen(n, box='bfov', near=False, alpha=(1, 100), beta=(1, 100), gamma=(-90, 90)):
+    g = R.gen.generate_boxes(n, (0, 360), (0, 180), alpha, beta, gamma, dtype='float', box=box)
+    if near:
+        sig = torch.tensor([8., 8., 6., 6., 10.])[:g.shape[1]]
+        p = g + torch.randn_like(g) * sig
+        p[:, 0] = p[:, 0] % 360
+        p[:, 1] = p[:, 1].clamp(0.5, 179.5)
+        p[:, 2:4] = p[:, 2:4].clamp(1, 170)
+        if g.shape[1] == 5:
+            p[:, 4] = p[:, 4].clamp(-89, 89)
+    else:
+        p = R.gen.generate_boxes(n, (0, 360), (0, 180), alpha, beta, gamma, dtype='float', box=box)
+    return g, p
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        out[k] = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, {k: tuple(v.shape) for k, v in out.items()})
+
+
+def iou_set(name, b1, b2, variants, aligned=True):
+    arrs = dict(b1=b1, b2=b2)
+    for v in variants:
+        arrs['iou_' + v] = IOU[v](b1, b2, is_aligned=aligned)
+        arrs['iou64_' + v] = f64(IOU[v], b1, b2, is_aligned=aligned)
+        t1, t2 = TRANS[v](b1.clone(), b2.clone(), rbb_angle_version='rad')
+        arrs['planar1_' + v], arrs['planar2_' + v] = t1, t2
+    save(name, **arrs)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(20231024)
+
+    # 1. the reference's own hard-coded sample pairs: tests/test_all_ious.py:244-261 (after geo2sph)
+    b1 = torch.tensor([[40, 50, 35, 55], [30, 60, 60, 60], [50, -78, 25, 46], [30, 75, 30, 60], [40, 70, 25, 30],
+                       [30, 75, 30, 30], [30, 60, 60, 60]]).float()
+    b2 = torch.tensor([[35, 20, 37, 50], [55, 40, 60, 60], [30, -75, 26, 45], [60, 40, 60, 60], [60, 85, 30, 30],
+                       [60, 55, 40, 50], [60, 60, 60, 60]]).float()
+    iou_set('samples7', R.box_formator.geo2sph(b1), R.box_formator.geo2sph(b2), ['standard', 'efficient', 'legacy'])
+
+    # 2. edge cases incl. identical / seam / pole / antipodal / contained / clamped alpha
+    e1 = torch.tensor([[100, 80, 40, 30], [1, 90, 30, 30], [10, 2, 30, 30], [10, 60, 50, 50], [100, 90, 60, 60],
+                       [100, 90, 60, 20], [100, 90, 200, 20], [0, 0, 10, 10], [359.9999, 179.9999, 10, 10],
+                       [180, 90, 1, 1], [180, 90, 179, 179], [20, 40, 30, 30]]).float()
+    e2 = torch.tensor([[100, 80, 40, 30], [359, 90, 30, 30], [200, 2, 30, 30], [190, 120, 50, 50],
+                       [100, 90, 20, 20], [100, 90, 20, 60], [120, 90, 200, 20], [0, 0, 10, 10],
+                       [0.0001, 179.9999, 10, 10], [180.5, 90.2, 1, 1], [181, 91, 179, 179],
+                       [20.00005, 40, 30, 30]]).float()
+    arrs = dict(b1=e1, b2=e2)
+    for v in IOU:
+        arrs['iou_' + v] = IOU[v](e1, e2, is_aligned=True)
+        arrs['iof_' + v] = IOU[v](e1, e2, mode='iof', is_aligned=True)
+    save('edge_cases', **arrs)
+
+    # 3. seeded random sets, BFoV: uniform (benchmark distribution), detector-like nearby, integer degrees
+    g, p = gen(2000)
+    iou_set('uniform_bfov', g, p, ['standard', 'efficient', 'legacy'])
+    g, p = gen(2000, near=True)
+    iou_set('nearby_bfov', g, p, ['standard', 'efficient', 'legacy'])
+    gi = R.gen.generate_boxes(1500, (0, 360), (1, 180), (1, 100), (1, 100), dtype='int')
+    pi = (gi + torch.randint(-6, 7, gi.shape).float())
+    pi[:, 0] = pi[:, 0] % 360
+    pi[:, 1] = pi[:, 1].clamp(1, 179)
+    pi[:, 2:] = pi[:, 2:].clamp(1, 170)
+    iou_set('int_bfov', gi, pi, ['standard', 'efficient', 'legacy'])
+
+    # 4. RBFoV (5-DoF)
+    g, p = gen(2000, box='rbfov')
+    iou_set('uniform_rbfov', g, p, ['standard', 'efficient'])
+    g, p = gen(2000, box='rbfov', near=True)
+    iou_set('nearby_rbfov', g, p, ['standard', 'efficient'])
+
+    # 5. options: rbb_edge x rbb_angle x mode on nearby pairs
+    g, p = gen(300, near=True)
+    g5, p5 = gen(300, box='rbfov', near=True)
+    arrs = dict(b1=g, b2=p, r1=g5, r2=p5)
+    for v in ('standard', 'efficient'):
+        for edge in ('arc', 'chord', 'tangent'):
+            for ang in ('equator', 'project'):
+                for mode in ('iou', 'iof'):
+                    key = f'{v}_{edge}_{ang}_{mode}'
+                    arrs['bfov_' + key] = IOU[v](g, p, mode=mode, is_aligned=True, rbb_edge=edge, rbb_angle=ang)
+                    arrs['rbfov_' + key] = IOU[v](g5, p5, mode=mode, is_aligned=True, rbb_edge=edge, rbb_angle=ang)
+    for edge in ('arc', 'chord', 'tangent'):
+        for mode in ('iou', 'iof'):
+            arrs[f'bfov_legacy_{edge}_equator_{mode}'] = IOU['legacy'](g, p, mode=mode, is_aligned=True, rbb_edge=edge)
+    save('options', **arrs)
+
+    # 6. pairwise (rows = first argument), incl. the MaxIoUAssigner call pattern iou(gt, anchors)
+    a, _ = gen(7)
+    b, _ = gen(11, near=False)
+    b[:7] = a + torch.randn(7, 4) * 3
+    b[:, 1] = b[:, 1].clamp(1, 179)
+    b[:, 2:] = b[:, 2:].clamp(1, 170)
+    arrs = dict(b1=a, b2=b)
+    for v in IOU:
+        arrs['iou_' + v] = IOU[v](a, b, is_aligned=False)
+    a5, _ = gen(5, box='rbfov')
+    b5 = a5[[0, 1, 2, 3, 4, 0, 2]] + torch.randn(7, 5) * 4
+    b5[:, 1] = b5[:, 1].clamp(1, 179)
+    b5[:, 2:4] = b5[:, 2:4].clamp(1, 170)
+    arrs.update(r1=a5, r2=b5)
+    for v in ('standard', 'efficient'):
+        arrs['riou_' + v] = IOU[v](a5, b5, is_aligned=False)
+    save('pairwise', **arrs)
+
+    # 7. planar rotated boxes -> vendored diff_iou_rotated_2d (sphdet/iou/diff_iou_rotated.py:325-343)
+    n = 3000
+    c = torch.randn(n, 2) * 0.3
+    p1 = torch.cat([c, torch.rand(n, 2) * 1.5 + 0.02, (torch.rand(n, 1) - 0.5) * 6.2], 1)
+    p2 = torch.cat([c + torch.randn(n, 2) * 0.3, torch.rand(n, 2) * 1.5 + 0.02, (torch.rand(n, 1) - 0.5) * 6.2], 1)
+    save('planar', p1=p1, p2=p2, iou=R.diff.diff_iou_rotated_2d(p1[None], p2[None])[0],
+         iou64=f64(R.diff.diff_iou_rotated_2d, p1[None], p2[None])[0])
+
+    # 8. losses: values + grads for iou/giou/diou/ciou; BFoV & RBFoV; weights / avg_factor / reductions
+    for box, dim in (('bfov', 4), ('rbfov', 5)):
+        tgt, pred = gen(400, box=box, near=True, alpha=(5, 90), beta=(5, 90), gamma=(-60, 60))
+        arrs = dict(pred=pred, target=tgt)
+        for mode in ('iou', 'giou', 'diou', 'ciou'):
+            L = R.iou_loss.Sph2PobIoULoss(mode=mode, reduction='none')
+            pr = pred.clone().requires_grad_(True)
+            tg = tgt.clone().requires_grad_(True)
+            el = L(pr, tg)
+            el.sum().backward()
+            arrs[f'loss_{mode}'] = el
+            arrs[f'gpred_{mode}'] = pr.grad
+            arrs[f'gtarget_{mode}'] = tg.grad
+            el64 = f64(lambda a, b: L(a, b), pred, tgt)
+            arrs[f'loss64_{mode}'] = el64
+        w1 = torch.rand(400)
+        w2 = torch.rand(400, dim)
+        arrs.update(w1=w1, w2=w2)
+        Lm = R.iou_loss.Sph2PobIoULoss(mode='ciou', reduction='mean', loss_weight=2.0)
+        arrs['mean_ciou'] = Lm(pred, tgt)
+        arrs['mean_ciou_w1'] = Lm(pred, tgt, w1)
+        arrs['mean_ciou_w2'] = Lm(pred, tgt, w2)
+        arrs['mean_ciou_w2_avg'] = Lm(pred, tgt, w2, avg_factor=123.0)
+        arrs['sum_ciou_w1'] = Lm(pred, tgt, w1, reduction_override='sum')
+        pr = pred.clone().requires_grad_(True)
+        Lm(pr, tgt, w2, avg_factor=123.0).backward()
+        arrs['gpred_mean_ciou_w2_avg'] = pr.grad
+        save('loss_' + box, **arrs)
+
+    # 9. NMS: the reference's 10-box scenario (tests/test_nms.py:6-27) + a seeded random scene
+    boxes = torch.tensor([[20, 40, 30, 30], [20, 40, 30, 30], [22, 38, 32, 28], [60, 60, 10, 10], [60, 60, 10, 10],
+                          [60, 60, 10, 10], [60, 60, 10, 10], [30, 10, 10, 10], [30, 45, 45, 45],
+                          [80, 20, 66, 66]]).float()
+    scores = torch.tensor([0.9, 0.8, 0.7, 0.6, 0.5, 0.85, 0.75, 0.65, 0.4, 0.3])
+    idxs = torch.tensor([1, 1, 1, 1, 1, 2, 2, 2, 3, 3])
+    nms = R.nms.SphNMS('sph2pob_efficient')
+    dets, keep = nms(boxes, scores, idxs, dict(type='nms', iou_threshold=0.5))
+    arrs = dict(boxes=boxes, scores=scores, idxs=idxs, dets=dets, keep=keep)
+    centers, _ = gen(40, alpha=(5, 60), beta=(5, 60))
+    rb = centers[torch.randint(0, 40, (400,))] + torch.randn(400, 4) * 2.5
+    rb[:, 0] = rb[:, 0] % 360
+    rb[:, 1] = rb[:, 1].clamp(1, 179)
+    rb[:, 2:] = rb[:, 2:].clamp(2, 120)
+    rs = torch.rand(400)
+    ri = torch.randint(0, 5, (400,))
+    dets, keep = nms(rb, rs, ri, dict(type='nms', iou_threshold=0.5, max_num=100))
+    arrs.update(rboxes=rb, rscores=rs, ridxs=ri, rdets=dets, rkeep=keep)
+    c5, _ = gen(30, box='rbfov', alpha=(5, 60), beta=(5, 60), gamma=(-60, 60))
+    rb5 = c5[torch.randint(0, 30, (300,))] + torch.randn(300, 5) * 2.5
+    rb5[:, 0] = rb5[:, 0] % 360
+    rb5[:, 1] = rb5[:, 1].clamp(1, 179)
+    rb5[:, 2:4] = rb5[:, 2:4].clamp(2, 120)
+    rs5 = torch.rand(300)
+    ri5 = torch.randint(0, 4, (300,))
+    dets, keep = nms(rb5, rs5, ri5, dict(type='nms', iou_threshold=0.4))
+    arrs.update(r5boxes=rb5, r5scores=rs5, r5idxs=ri5, r5dets=dets, r5keep=keep)
+    save('nms', **arrs)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,241 @@
+"""ORACLE — test infrastructure only (numpy + ctypes front end of oracle/sph2pob_oracle.c).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module.
+The product package ``sph_retina_amd`` never imports anything from ``oracle/``.
+
+Host-side pieces restated here in numpy (each cites the reference file:line it follows):
+  * ``weight_reduce_loss``  — mmdet/models/losses/utils.py:30-59
+  * ``OBBIoULoss.forward`` + ``Sph2PobTransfrom`` weight widening — sphdet/losses/sph2pob_iou_loss.py:25-58,
+    sphdet/losses/sph2pob_transform.py:32-34
+  * ``sph_nms_op`` / ``sph_batched_nms`` — sphdet/bbox/nms/sph_nms.py:22-74
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, '_build', 'libsph2pob_oracle.so')
+
+VARIANTS = {'standard': 0, 'efficient': 1, 'legacy': 2}
+MODES = {'iou': 0, 'iof': 1}
+EDGES = {'arc': 0, 'chord': 1, 'tangent': 2}
+ANGLES = {'equator': 0, 'project': 1, None: 0}
+PLANARS = {'mmcv': 0, 'diff': 1, 'exact': 2}
+LOSS_MODES = {'iou': 0, 'giou': 1, 'diou': 2, 'ciou': 3}
+
+
+def build(force=False):
+    """Compile the C oracle (gcc).  Building the checker is not using it."""
+    if force or not os.path.exists(_SO) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_SO)
+            for f in ('sph2pob_oracle.c', 'sph2pob_oracle_impl.h', 'sph2pob_oracle.h')):
+        subprocess.check_call(['make', '-C', _HERE, '-s'] + (['-B'] if force else []))
+    return _SO
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        build()
+        _LIB = ctypes.CDLL(_SO)
+    return _LIB
+
+
+def max_threads():
+    return int(lib().sph2pob_oracle_max_threads())
+
+
+def _np(a, dtype):
+    return np.ascontiguousarray(np.asarray(a, dtype=dtype))
+
+
+def _suffix(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return 'f32', ctypes.c_float
+    if dtype == np.float64:
+        return 'f64', ctypes.c_double
+    raise TypeError(dtype)
+
+
+def _ptr(a, ct):
+    return a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+def iou_aligned(b1, b2, variant='standard', mode='iou', edge='arc', angle='equator', planar='mmcv',
+                dtype=np.float32, nthreads=1):
+    suf, ct = _suffix(dtype)
+    b1, b2 = _np(b1, dtype), _np(b2, dtype)
+    assert b1.shape == b2.shape and b1.ndim == 2
+    n, dim = b1.shape
+    out = np.empty(n, dtype=dtype)
+    rc = getattr(lib(), 'sph2pob_oracle_iou_aligned_' + suf)(
+        _ptr(b1, ct), _ptr(b2, ct), _ptr(out, ct), ctypes.c_int64(n), dim, VARIANTS[variant], MODES[mode],
+        EDGES[edge], ANGLES[angle], PLANARS[planar], int(nthreads))
+    if rc != 0:
+        raise ValueError('oracle rc=%d' % rc)
+    return out
+
+
+def iou_pairwise(b1, b2, variant='standard', mode='iou', edge='arc', angle='equator', planar='mmcv',
+                 dtype=np.float32, nthreads=1):
+    suf, ct = _suffix(dtype)
+    b1, b2 = _np(b1, dtype), _np(b2, dtype)
+    m, dim = b1.shape
+    n = b2.shape[0]
+    assert b2.shape[1] == dim
+    out = np.empty((m, n), dtype=dtype)
+    rc = getattr(lib(), 'sph2pob_oracle_iou_pairwise_' + suf)(
+        _ptr(b1, ct), ctypes.c_int64(m), _ptr(b2, ct), ctypes.c_int64(n), _ptr(out, ct), dim, VARIANTS[variant],
+        MODES[mode], EDGES[edge], ANGLES[angle], PLANARS[planar], int(nthreads))
+    if rc != 0:
+        raise ValueError('oracle rc=%d' % rc)
+    return out
+
+
+def transform(b1, b2, variant='standard', edge='arc', angle='equator', jitter=False, dtype=np.float32):
+    """Planar boxes (x, y, w, h, a[rad]) of both roles; with ``jitter`` both jitters are applied around it."""
+    suf, ct = _suffix(dtype)
+    b1, b2 = _np(b1, dtype), _np(b2, dtype)
+    n, dim = b1.shape
+    o1 = np.empty((n, 5), dtype=dtype)
+    o2 = np.empty((n, 5), dtype=dtype)
+    rc = getattr(lib(), 'sph2pob_oracle_transform_' + suf)(
+        _ptr(b1, ct), _ptr(b2, ct), _ptr(o1, ct), _ptr(o2, ct), ctypes.c_int64(n), dim, VARIANTS[variant],
+        EDGES[edge], ANGLES[angle], int(bool(jitter)))
+    if rc != 0:
+        raise ValueError('oracle rc=%d' % rc)
+    return o1, o2
+
+
+def planar_iou(p1, p2, mode='iou', planar='mmcv', dtype=np.float32):
+    suf, ct = _suffix(dtype)
+    p1, p2 = _np(p1, dtype), _np(p2, dtype)
+    n = p1.shape[0]
+    out = np.empty(n, dtype=dtype)
+    getattr(lib(), 'sph2pob_oracle_planar_iou_' + suf)(_ptr(p1, ct), _ptr(p2, ct), _ptr(out, ct),
+                                                         ctypes.c_int64(n), MODES[mode], PLANARS[planar])
+    return out
+
+
+def loss_elements(pred, target, mode='iou', eps=1e-6, dtype=np.float32, nthreads=1, return_iou=False):
+    """Per-pair unweighted Sph2PobIoULoss element (sph2pob_transform.py:24-35 + sph2pob_iou_loss.py:104-196)."""
+    suf, ct = _suffix(dtype)
+    pred, target = _np(pred, dtype), _np(target, dtype)
+    n, dim = pred.shape
+    loss = np.empty(n, dtype=dtype)
+    iou = np.empty(n, dtype=dtype)
+    rc = getattr(lib(), 'sph2pob_oracle_loss_' + suf)(
+        _ptr(pred, ct), _ptr(target, ct), _ptr(loss, ct), _ptr(iou, ct), ctypes.c_int64(n), dim, LOSS_MODES[mode],
+        ctypes.c_double(eps), int(nthreads))
+    if rc != 0:
+        raise ValueError('oracle rc=%d' % rc)
+    return (loss, iou) if return_iou else loss
+
+
+def weight_reduce_loss(loss, weight=None, reduction='mean', avg_factor=None):
+    """mmdet/models/losses/utils.py:30-59 (numpy, dtype of ``loss``)."""
+    dt = loss.dtype
+    if weight is not None:
+        loss = loss * np.asarray(weight, dtype=dt)
+    if avg_factor is None:
+        if reduction == 'none':
+            return loss
+        if reduction == 'mean':
+            return loss.mean(dtype=dt)
+        if reduction == 'sum':
+            return loss.sum(dtype=dt)
+        raise ValueError(reduction)
+    if reduction == 'mean':
+        eps = np.finfo(np.float32).eps
+        return loss.sum(dtype=dt) / dt.type(avg_factor + eps)
+    if reduction != 'none':
+        raise ValueError('avg_factor can not be used with reduction="sum"')
+    return loss
+
+
+def sph2pob_iou_loss(pred, target, weight=None, avg_factor=None, mode='iou', eps=1e-6, reduction='mean',
+                     loss_weight=1.0, dtype=np.float32):
+    """Sph2PobIoULoss.forward value (sph2pob_transform.py:24-35 then sph2pob_iou_loss.py:25-58)."""
+    pred, target = _np(pred, dtype), _np(target, dtype)
+    box_version = target.shape[-1]
+    if weight is not None:
+        weight = _np(weight, dtype)
+        if weight.ndim > 1 and box_version == 4:
+            weight = np.concatenate([weight, weight.mean(-1, keepdims=True)], axis=-1)
+        if not np.any(weight > 0):
+            return np.dtype(dtype).type(0.0)
+        if weight.ndim > 1:
+            weight = weight.mean(-1)
+    el = loss_elements(pred, target, mode=mode, eps=eps, dtype=dtype)
+    return np.dtype(dtype).type(loss_weight) * weight_reduce_loss(el, weight, reduction, avg_factor)
+
+
+def loss_grad_fd(pred, target, mode='iou', eps=1e-6, h=1e-5):
+    """fp64 central finite differences of the per-pair loss element w.r.t. pred and target (degrees).
+    Independent check for the hand-derived HIP adjoint; only meaningful away from the kinks of the loss."""
+    pred = _np(pred, np.float64)
+    target = _np(target, np.float64)
+    n, dim = pred.shape
+    gp = np.zeros_like(pred)
+    gt = np.zeros_like(target)
+    for k in range(dim):
+        for arr, g in ((pred, gp), (target, gt)):
+            save = arr[:, k].copy()
+            arr[:, k] = save + h
+            lp = loss_elements(pred, target, mode, eps, np.float64)
+            arr[:, k] = save - h
+            lm = loss_elements(pred, target, mode, eps, np.float64)
+            arr[:, k] = save
+            g[:, k] = (lp - lm) / (2 * h)
+    return gp, gt
+
+
+def nms_op(boxes, scores, iou_threshold, variant='efficient', planar='mmcv'):
+    """sph_nms_op: sphdet/bbox/nms/sph_nms.py:62-74.  Stable descending sort (ties keep input order)."""
+    boxes = _np(boxes, np.float32)
+    order = np.argsort(-np.asarray(scores, dtype=np.float32), kind='stable')
+    keep = []
+    while order.size > 0:
+        keep.append(order[0])
+        if order.size == 1:
+            break
+        iou = iou_pairwise(boxes[order[:1]], boxes[order[1:]], variant=variant, planar=planar).reshape(-1)
+        order = order[1:][iou <= np.float32(iou_threshold)]
+    return np.asarray(keep, dtype=np.int64)
+
+
+def batched_nms(boxes, scores, idxs, iou_threshold=0.5, max_num=None, variant='efficient', planar='mmcv'):
+    """sph_batched_nms: sphdet/bbox/nms/sph_nms.py:22-60 -> (dets (K', d+1), keep (K',))."""
+    boxes = _np(boxes, np.float32)
+    scores = _np(scores, np.float32)
+    idxs = np.asarray(idxs)
+    total = np.zeros(scores.shape, dtype=bool)
+    for c in np.unique(idxs):
+        m = np.nonzero(idxs == c)[0]
+        k = nms_op(boxes[m], scores[m], iou_threshold, variant, planar)
+        total[m[k]] = True
+    keep = np.nonzero(total)[0]
+    inds = np.argsort(-scores[keep], kind='stable')
+    keep = keep[inds]
+    max_num = boxes.shape[0] if max_num is None else min(max_num, boxes.shape[0])
+    keep = keep[:max_num]
+    dets = np.concatenate([boxes[keep], scores[keep, None]], axis=-1)
+    return dets, keep.astype(np.int64)
+
+
+def generate_boxes(n, seed, box='bfov', alpha=(1, 100), beta=(1, 100), gamma=(-90, 90), theta=(0, 360),
+                   phi=(0, 180)):
+    """Synthetic boxes of the shape of tests/utils/generate_data.py:31-42 (dtype='float'), numpy RNG."""
+    rng = np.random.default_rng(seed)
+    u = rng.random((n, 5), dtype=np.float32)
+    cols = [u[:, 0] * (theta[1] - theta[0]) + theta[0], u[:, 1] * (phi[1] - phi[0]) + phi[0],
+            u[:, 2] * (alpha[1] - alpha[0]) + alpha[0], u[:, 3] * (beta[1] - beta[0]) + beta[0]]
+    if box == 'rbfov':
+        cols.append(u[:, 4] * (gamma[1] - gamma[0]) + gamma[0])
+    return np.stack(cols, axis=1).astype(np.float32)
