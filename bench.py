@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py — Sph2Pob spherical-IoU throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch of synthetic boxes resident in HBM:
+aligned `sph2pob_standard_iou` over 1,000,000 BFoV pairs per GPU (BASELINE.json configs[1]); for N > 1 every
+rank owns its own 1 M-pair shard (N = 8 is configs[4]: 8 M pairs sharded 8x) and the per-shard IoU vectors are
+assembled on every rank with ONE RCCL all_gather_into_tensor on the compute stream, inside the timed step.
+`value` = pairs processed by all ranks / max-over-ranks wall time.  Weak scaling (per-GPU work fixed).
+
+Extra objects on the JSON line:
+  roofline      the dominant kernel (iou_aligned) against the HBM roofline: algorithmic bytes = 36 B/pair
+                (2 x 16 B boxes in + 4 B IoU out) / average launch duration measured here with
+                HIP events on the launch stream; `traffic` = PMC-measured HBM bytes per launch when
+                profiles/ holds a summary for this round (collected in separate rocprofv3 --pmc passes), else null.
+  cpu_baseline  the CPU oracle (C restatement of the reference path, "port") timed on this host's cores on a
+                bounded sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PAIRS_PER_GPU = 1_000_000
+BYTES_PER_PAIR = 36          # aligned BFoV: 2 * 16 B read + 4 B written
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+VARIANT = 'standard'
+
+
+def make_boxes(n, seed, device):
+    """tests/utils/generate_data.py:31-42 (dtype='float') with the harness ranges of tests/test_all_ious.py:141-147."""
+    import torch
+    g = torch.Generator(device='cpu')
+    g.manual_seed(seed)
+    u = torch.rand((n, 4), generator=g)
+    boxes = torch.stack([u[:, 0] * 360, u[:, 1] * 180, u[:, 2] * 99 + 1, u[:, 3] * 99 + 1], dim=1)
+    return boxes.to(device)
+
+
+def cpu_baseline(n_sample=1_000_000):
+    """Oracle timed on the host: the checker used as a reported baseline, never as the thing shipped."""
+    import numpy as np
+    from oracle import oracle as O
+    O.build()
+    b1 = O.generate_boxes(n_sample, 0)
+    b2 = O.generate_boxes(n_sample, 1)
+    cores = min(O.max_threads(), len(os.sched_getaffinity(0)))
+    O.iou_aligned(b1[:20000], b2[:20000], variant=VARIANT, planar='mmcv', nthreads=cores)  # spin up the pool
+    reps, t_total = 0, 0.0
+    while t_total < 10.0 and reps < 64:   # ~10 s of CPU work, bounded
+        t0 = time.perf_counter()
+        O.iou_aligned(b1, b2, variant=VARIANT, planar='mmcv', nthreads=cores)
+        t_total += time.perf_counter() - t0
+        reps += 1
+    t1 = time.perf_counter()
+    O.iou_aligned(b1[:200000], b2[:200000], variant=VARIANT, planar='mmcv', nthreads=1)
+    single = 200000 / (time.perf_counter() - t1)
+    return {'value': reps * n_sample / t_total, 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{reps} x {n_sample} uniform BFoV pairs, sph2pob_{VARIANT}_iou, C oracle (OpenMP)',
+            'single_core_pairs_per_s': single}
+
+
+def pmc_traffic():
+    """HBM bytes per launch from the committed PMC summary of this round (profiles/pmc_summary.json)."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
+    try:
+        with open(path) as f:
+            return json.load(f).get('iou_aligned', {}).get('hbm_bytes_per_launch')
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--pairs', type=int, default=PAIRS_PER_GPU, help='pairs per GPU per step')
+    ap.add_argument('--variant', default=VARIANT, choices=['standard', 'efficient', 'legacy'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from sph_retina_amd import _lib, _torch_glue as G
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    n = args.pairs
+    b1 = make_boxes(n, 2 * rank, dev)        # rank r owns its own contiguous shard, generated per rank
+    b2 = make_boxes(n, 2 * rank + 1, dev)
+    gathered = torch.empty(world * n, dtype=torch.float32, device=dev)
+    shard = gathered[rank * n:(rank + 1) * n]  # the kernel writes straight into its slot of the gathered vector
+    lib = _lib.lib()
+    stream = torch.cuda.current_stream(dev)
+    variant_c = G.VARIANTS[args.variant]
+
+    def step():
+        rc = lib.sph2pob_iou_aligned_f32(G.ptr(b1), G.ptr(b2), G.ptr(shard), ctypes.c_int64(n), 4, variant_c, 0, 0, 0,
+                                         ctypes.c_void_p(stream.cuda_stream))
+        if rc:
+            _lib.check(rc, 'sph2pob_iou_aligned_f32')
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, shard)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant-kernel duration: HIP events on the launch stream around K back-to-back launches (no collective)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    k_launch = max(args.steps, 50)
+    torch.cuda.synchronize(dev)
+    ev0.record(stream)
+    for _ in range(k_launch):
+        lib.sph2pob_iou_aligned_f32(G.ptr(b1), G.ptr(b2), G.ptr(shard), ctypes.c_int64(n), 4, variant_c, 0, 0, 0,
+                                    ctypes.c_void_p(stream.cuda_stream))
+    ev1.record(stream)
+    torch.cuda.synchronize(dev)
+    kernel_ms = ev0.elapsed_time(ev1) / k_launch
+    checksum = float(shard.double().sum().item())
+
+    if rank == 0:
+        achieved = BYTES_PER_PAIR * n / (kernel_ms * 1e-3) / 1e9
+        out = {
+            'metric': 'box-pairs/sec, Sph2Pob spherical IoU (aligned BFoV, fp32), 1M pairs per MI355X',
+            'value': world * n * args.steps / elapsed,
+            'unit': 'pairs/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,   # BASELINE.json:published is empty (README T_cuda has no stated hardware)
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': f'{n:,} uniform random BFoV pairs per GPU, sph2pob_{args.variant}_iou aligned '
+                                   f'(BASELINE configs[1]{"; x%d shards + RCCL all-gather = configs[4]" % world if world > 1 else ""})',
+                       'pairs_per_gpu': n, 'variant': args.variant, 'parallelism': f'shard{world}'},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(),
+                         'kernel': 'iou_aligned_kernel', 'kernel_ms': kernel_ms,
+                         'algorithmic_bytes_per_launch': BYTES_PER_PAIR * n},
+            'readme_t_cuda_ratio': (n / (kernel_ms * 1e-3)) / (1e6 / 0.0096),
+            'checksum': checksum,
+        }
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,80 @@
+/*
+ * sph2pob_hip.h — C ABI of libsph2pob_hip.so: the MI355X (gfx950) Sph2Pob spherical-IoU engine.
+ *
+ * The reference (ManuelVeras/sph-retina) has no FFI of its own: its hot path is Python that calls torch
+ * element-wise ops plus three compiled mmcv-full 1.6.0 ops.  Each entry point below names the reference
+ * interface it replaces (paths relative to the reference checkout).  A maintainer binds these from Python
+ * with ctypes; no torch types cross this boundary.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless stated; row-major, contiguous, fp32 ("f32") / int64
+ *   - boxes are degrees: BFoV (theta, phi, alpha, beta) box_dim = 4; RBFoV (+gamma) box_dim = 5
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); launchers only ENQUEUE:
+ *     no allocation, no synchronisation, no ownership transfer, inputs are never written
+ *   - return value: 0 on success, a negative SPH2POB_ERR_* for bad arguments, or a positive hipError_t
+ */
+#ifndef SPH2POB_HIP_H
+#define SPH2POB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* transform variant: sphdet/iou/sph_iou_api.py:91-98 (sph2pob_{standard,efficient,legacy}_iou) */
+enum { SPH2POB_VARIANT_STANDARD = 0, SPH2POB_VARIANT_EFFICIENT = 1, SPH2POB_VARIANT_LEGACY = 2 };
+/* mode: sphdet/iou/sph_iou_api.py:49 ('iou' | 'iof') */
+enum { SPH2POB_MODE_IOU = 0, SPH2POB_MODE_IOF = 1 };
+/* rbb_edge: sphdet/iou/sph2pob_standard.py:110-118 */
+enum { SPH2POB_EDGE_ARC = 0, SPH2POB_EDGE_CHORD = 1, SPH2POB_EDGE_TANGENT = 2 };
+/* rbb_angle: sphdet/iou/sph2pob_standard.py:88-108 */
+enum { SPH2POB_ANGLE_EQUATOR = 0, SPH2POB_ANGLE_PROJECT = 1 };
+/* loss mode: sphdet/losses/sph2pob_iou_loss.py:19 */
+enum { SPH2POB_LOSS_IOU = 0, SPH2POB_LOSS_GIOU = 1, SPH2POB_LOSS_DIOU = 2, SPH2POB_LOSS_CIOU = 3 };
+
+enum {
+    SPH2POB_OK = 0,
+    SPH2POB_ERR_NULL = -1,    /* a required pointer is NULL while the element count is > 0 */
+    SPH2POB_ERR_DIM = -2,     /* box_dim not in {4, 5}, or legacy variant with box_dim 5 (reference raises) */
+    SPH2POB_ERR_OPTION = -3,  /* variant / mode / edge / angle / loss mode out of range */
+    SPH2POB_ERR_SIZE = -4     /* negative count or a product that overflows the launch geometry */
+};
+
+/* Library identification: ABI version (bumped on any signature change) and the code-object target. */
+int sph2pob_abi_version(void);
+const char* sph2pob_target_arch(void);
+const char* sph2pob_error_string(int code);
+
+/*
+ * Aligned Sph2Pob IoU: out[i] = clamp(IoU(b1[i], b2[i]), 0, 1), i < n.
+ * Replaces _sph2pob_iou_auxiliary(..., is_aligned=True) = jitter -> transform -> jitter -> mmcv
+ * box_iou_rotated -> clamp: sphdet/iou/sph_iou_api.py:48-86 (and the wrappers at :91-98).
+ * b1, b2: (n, box_dim) f32; out: (n) f32.  Algorithmic HBM traffic: 2*4*box_dim + 4 bytes per pair.
+ */
+int sph2pob_iou_aligned_f32(const float* b1, const float* b2, float* out, int64_t n, int box_dim, int variant,
+                            int mode, int edge, int angle, void* stream);
+
+/*
+ * Pairwise Sph2Pob IoU: out[i*n + j] = clamp(IoU(b1[i], b2[j]), 0, 1); rows = first argument, exactly the
+ * (rows, cols) view of sphdet/iou/sph_iou_api.py:59-64,85 without materialising the m*n expanded pairs.
+ * This is the call MaxIoUAssigner makes: overlaps = iou_calculator(gt_bboxes, bboxes)
+ * (mmdet/core/bbox/assigners/max_iou_assigner.py:113).
+ */
+int sph2pob_iou_pairwise_f32(const float* b1, int64_t m, const float* b2, int64_t n, float* out, int box_dim,
+                             int variant, int mode, int edge, int angle, void* stream);
+
+/*
+ * Planar oriented boxes of both roles, (n, 5) f32 each = (x, y, w, h, a[rad]); with jitter != 0 the spherical
+ * and rotated jitters are applied around the transform exactly as Sph2PobTransfrom.new_forward does
+ * (sphdet/losses/sph2pob_transform.py:26-30) — the shared front end of every Sph2Pob-wrapped OBB loss.
+ * Replaces sph2pob_{standard,efficient,legacy}(sph_gt, sph_pred, rbb_angle_version='rad', ...):
+ * sphdet/iou/sph2pob_standard.py:8-80, sph2pob_efficient.py:9-73, sph2pob_legacy.py:8-31.
+ */
+int sph2pob_transform_f32(const float* b1, const float* b2, float* planar1, float* planar2, int64_t n,
+                          int box_dim, int variant, int edge, int angle, int jitter, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPH2POB_HIP_H */

@@ -1,0 +1,99 @@
+"""ctypes binding of libsph2pob_hip.so (the C ABI declared in include/sph2pob_hip.h).
+
+There is no CPU fallback and no torch extension: if the shared library is missing or a symbol is absent the
+import of the product fails loudly.  ``build()`` cross-compiles the library for gfx950 with hipcc (works
+without a GPU); the built .so lives in-tree under sph_retina_amd/lib/ so it travels with the source tree.
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_DIR = os.path.join(_HERE, 'lib')
+LIB_PATH = os.path.join(LIB_DIR, 'libsph2pob_hip.so')
+SOURCES = ['sph2pob_kernels.hip']
+HEADERS = ['sph2pob_device.hpp', os.path.join('..', '..', 'include', 'sph2pob_hip.h')]
+HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off']
+
+_c_f32p = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+
+# name -> argtypes (restype is always int unless listed in _RESTYPES); mirrors include/sph2pob_hip.h
+SIGNATURES = {
+    'sph2pob_abi_version': [],
+    'sph2pob_target_arch': [],
+    'sph2pob_error_string': [_int],
+    'sph2pob_iou_aligned_f32': [_c_f32p, _c_f32p, _c_f32p, _i64, _int, _int, _int, _int, _int, ctypes.c_void_p],
+    'sph2pob_iou_pairwise_f32': [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _int, _int, _int, _int, _int,
+                                 ctypes.c_void_p],
+    'sph2pob_transform_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _int, _int, _int, _int,
+                              ctypes.c_void_p],
+}
+_RESTYPES = {'sph2pob_target_arch': ctypes.c_char_p, 'sph2pob_error_string': ctypes.c_char_p}
+
+ABI_VERSION = 1
+
+
+class Sph2PobLibraryError(RuntimeError):
+    pass
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 ... -> sph_retina_amd/lib/libsph2pob_hip.so (no GPU needed)."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        raise Sph2PobLibraryError('hipcc not found: cannot build libsph2pob_hip.so')
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc] + HIPCC_FLAGS + ['-o', LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB_PATH
+
+
+_LIB = None
+
+
+def lib():
+    """The loaded library with typed entry points; raises Sph2PobLibraryError when it cannot be used."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise Sph2PobLibraryError(
+            f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(hipcc --offload-arch=gfx950).  There is no CPU / eager fallback for the Sph2Pob path.')
+    try:
+        handle = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise Sph2PobLibraryError(f'cannot load {LIB_PATH}: {e}') from e
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise Sph2PobLibraryError(f'{LIB_PATH} does not export {name}') from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, _int)
+    if handle.sph2pob_abi_version() != ABI_VERSION:
+        raise Sph2PobLibraryError('libsph2pob_hip.so ABI version mismatch: rebuild the library')
+    _LIB = handle
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().sph2pob_error_string(int(rc))
+        raise Sph2PobLibraryError(f'{what} failed: {msg.decode() if msg else rc} (code {rc})')

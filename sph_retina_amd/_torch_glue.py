@@ -1,0 +1,42 @@
+"""Thin torch <-> C-ABI plumbing: device checks, pointers, current stream.  PyTorch is used for device
+memory and streams only; all arithmetic happens in libsph2pob_hip.so."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+VARIANTS = {'standard': 0, 'efficient': 1, 'legacy': 2}
+MODES = {'iou': 0, 'iof': 1}
+EDGES = {'arc': 0, 'chord': 1, 'tangent': 2}
+ANGLES = {'equator': 0, 'project': 1}
+
+
+def require_hip(*tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError(
+                'sph_retina_amd runs on MI355X (HIP) tensors only; got a %s tensor. There is deliberately no '
+                'CPU fallback in the product path (use the reference or oracle/ for CPU checks).' % t.device)
+
+
+def as_f32(t):
+    """Contiguous fp32 view/copy (never the caller's storage when a conversion is needed)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else ctypes.c_void_p(0)
+
+
+def stream_of(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def call(name, device, *args):
+    """Enqueue a launcher on the current stream of `device` and translate its return code."""
+    with torch.cuda.device(device):
+        rc = getattr(_lib.lib(), name)(*args)
+    _lib.check(rc, name)

@@ -1,0 +1,338 @@
+// Sph2Pob device math for gfx950 (CDNA4).  One lane = one box pair; everything lives in VGPRs.
+//
+// What it computes (reference paths are relative to the reference checkout):
+//   jitter_spherical   sphdet/iou/sph_iou_api.py:244-260
+//   transform_*        sphdet/iou/sph2pob_standard.py:8-80, sph2pob_efficient.py:9-73, sph2pob_legacy.py:8-31
+//   jitter_rotated     sphdet/iou/sph_iou_api.py:222-242
+//   rect_intersection  replaces mmcv-full 1.6.0 box_iou_rotated (call site sph_iou_api.py:79)
+//
+// The transforms keep the reference's fp32 operation order (this translation unit is compiled with
+// -ffp-contract=off): the path is dominated by acos(clamp(dot)) of nearly parallel unit vectors, which
+// amplifies any re-association into >1e-5 IoU differences at small centre distances.
+//
+// The planar stage is NOT mmcv's algorithm (24 candidate points -> Graham scan with absolute 1e-6/1e-8
+// tolerances -> fan area: divergent, array-indexed, scratch-heavy on a GPU).  It is a branch-free boundary
+// integral: the boundary of A∩B is (edges of A inside B) ∪ (edges of B inside A); each of the 8 edges is
+// clipped against the other rectangle with a slab test in that rectangle's frame and contributes
+// (clipped length) x (signed distance of the edge line from the integration origin).  No sort, no hull, no
+// local arrays, IEEE inf/NaN semantics of v_rcp/v_min/v_max handle parallel edges.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sph2pob {
+
+enum : int { VARIANT_STANDARD = 0, VARIANT_EFFICIENT = 1, VARIANT_LEGACY = 2 };
+enum : int { MODE_IOU = 0, MODE_IOF = 1 };
+enum : int { EDGE_ARC = 0, EDGE_CHORD = 1, EDGE_TANGENT = 2 };
+enum : int { ANGLE_EQUATOR = 0, ANGLE_PROJECT = 1 };
+
+struct PBox { float x, y, w, h, a; };
+struct V3 { float x, y, z; };
+
+#define SPH_DEV __device__ __forceinline__
+
+// ---- constants, rounded to fp32 exactly like the reference's python-double -> float32 casts ----
+constexpr float kDeg2Rad = 0.017453292519943295f;       // torch.deg2rad scalar
+constexpr float kPi = 3.141592653589793f;               // torch.pi cast to fp32
+constexpr double kEpsS = 1e-4 * 1.2345678;              // spherical / rotated "similar" eps
+constexpr double kEpsA = 1e-3 * 1.2345678;              // rotated angle eps
+constexpr float kClampHi = (float)(1 - 1e-7);           // 0.99999988
+constexpr float kClampLo = (float)(-1 + 1e-7);
+
+SPH_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }  // NaN-free inputs
+
+SPH_DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+SPH_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+SPH_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+SPH_DEV float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+SPH_DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+// F.normalize: v / max(||v||, 1e-12)
+SPH_DEV V3 normalize(V3 a) {
+    float n = sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z);
+    float d = fmaxf(n, 1e-12f);
+    return v3(a.x / d, a.y / d, a.z / d);
+}
+// compute_angle_between_direction (radians): sph2pob_efficient.py:192-208
+SPH_DEV float angle_between(V3 a, V3 b) {
+    float c = clampf(dot(normalize(a), normalize(b)), kClampLo, kClampHi);
+    return fabsf(acosf(c));
+}
+SPH_DEV float rad2deg_ref(float r) { return r / kPi * 180.0f; }  // sph2pob_standard.py:216
+// compute_clockwise_or_anticlockwise_between_direction: sph2pob_efficient.py:211-226
+SPH_DEV float sign_mask(V3 a, V3 b, V3 ref) { return dot(cross(a, b), ref) < 0.0f ? 1.0f : -1.0f; }
+
+SPH_DEV float edge_length(float fov, int edge) {  // sph2pob_standard.py:110-118
+    if (edge == EDGE_ARC) return fov;
+    if (edge == EDGE_TANGENT) return 2.0f * tanf(fov / 2.0f);
+    return 2.0f * sinf(fov / 2.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// jiter_spherical_bboxes — sph_iou_api.py:244-260.  b1/b2 are register copies (inputs are never mutated).
+template <int DIM>
+SPH_DEV void jitter_spherical(float (&b1)[5], float (&b2)[5]) {
+    const float eps = (float)kEpsS, eps2 = (float)(2 * kEpsS);
+    bool similar = false;
+#pragma unroll
+    for (int k = 0; k < DIM; k++) similar |= fabsf(b1[k] - b2[k]) < eps;
+    if (similar) {
+#pragma unroll
+        for (int k = 0; k < DIM; k++) {
+            b1[k] = b1[k] - eps2;
+            b2[k] = b2[k] + eps;
+        }
+    }
+    b1[0] = clampf(b1[0], eps2, (float)(360.0 - kEpsS));
+    b2[0] = clampf(b2[0], eps, (float)(360.0 - 2 * kEpsS));
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+        b1[k] = clampf(b1[k], eps2, (float)(180.0 - kEpsS));
+        b2[k] = clampf(b2[k], eps, (float)(180.0 - 2 * kEpsS));
+    }
+    if (DIM == 5) {  // quirk kept: only bboxes2's gamma is clamped (twice) :256-258
+        b2[4] = clampf(b2[4], (float)(-360.0 + kEpsS), (float)(360.0 - 2 * kEpsS));
+        b2[4] = clampf(b2[4], (float)(-360.0 + 2 * kEpsS), (float)(360.0 - kEpsS));
+    }
+}
+
+// jiter_rotated_bboxes — sph_iou_api.py:222-242
+SPH_DEV void jitter_rotated(PBox& p1, PBox& p2) {
+    const float e = (float)kEpsS, e2 = (float)(2 * kEpsS), e5 = (float)(5 * kEpsS);
+    bool similar = (fabsf(p1.x - p2.x) < e) | (fabsf(p1.w - p2.w) < e) | (fabsf(p1.h - p2.h) < e) |
+                   (fabsf(p1.a - p2.a) < e);
+    if (similar) {
+        p1.x += e;  p1.y += e;  p1.w += e2; p1.h += e2; p1.a += e;
+        p2.x += e2; p2.y += e2; p2.w += e;  p2.h += e;  p2.a += e5;
+    }
+    const float ea = (float)kEpsA, ea2 = (float)(2 * kEpsA);
+    if (fabsf(p1.a - p2.a) < ea) {
+        p1.a += ea;
+        p2.a += ea2;
+    }
+    const double pi = 3.141592653589793;
+    p1.w = fmaxf(p1.w, (float)(2 * kEpsA / 10)); p1.h = fmaxf(p1.h, (float)(2 * kEpsA / 10));
+    p2.w = fmaxf(p2.w, (float)(kEpsA / 10));     p2.h = fmaxf(p2.h, (float)(kEpsA / 10));
+    p1.a = clampf(p1.a, (float)(-2 * pi + 2 * kEpsA), (float)(2 * pi - kEpsA));
+    p2.a = clampf(p2.a, (float)(-2 * pi + kEpsA), (float)(2 * pi - 2 * kEpsA));
+}
+
+// ------------------------------------------------------------------------------------------------
+struct SBox { float th, ph, al, be, ga, st, ct, sp, cp; V3 c, d; };
+
+template <int DIM>
+SPH_DEV SBox load_sbox(const float (&b)[5]) {  // sph2pob_standard.py:23-41, 121-172
+    SBox s;
+    s.th = b[0] * kDeg2Rad; s.ph = b[1] * kDeg2Rad; s.al = b[2] * kDeg2Rad; s.be = b[3] * kDeg2Rad;
+    s.ga = DIM == 5 ? b[4] * kDeg2Rad : 0.0f;
+    s.st = sinf(s.th); s.ct = cosf(s.th); s.sp = sinf(s.ph); s.cp = cosf(s.ph);
+    s.c = v3(s.sp * s.ct, s.sp * s.st, s.cp);
+    s.d = v3(s.cp * s.ct, s.cp * s.st, -s.sp);
+    return s;
+}
+
+struct M3 { V3 r0, r1, r2; };
+SPH_DEV V3 mul(const M3& m, V3 v) { return v3(dot(m.r0, v), dot(m.r1, v), dot(m.r2, v)); }
+// compute_rotate_matrix(theta, phi): rows look, down, right — sph2pob_standard.py:239-261
+SPH_DEV M3 rotate_matrix(float st, float ct, float sp, float cp) {
+    return M3{v3(sp * ct, sp * st, cp), v3(cp * ct, cp * st, -sp), v3(st, -ct, 0.0f)};
+}
+// dir <- T^T (Rx(gamma) T) dir — compute_gamma_matrix, sph2pob_standard.py:300-314 (matrix products kept)
+SPH_DEV V3 apply_gamma(const SBox& s, float gamma, V3 dir) {
+    M3 T = rotate_matrix(s.st, s.ct, s.sp, s.cp);
+    float sg = sinf(gamma), cg = cosf(gamma);
+    // RT = Rx * T  (rows)
+    M3 RT;
+    RT.r0 = T.r0;
+    RT.r1 = v3((0.0f * T.r0.x + cg * T.r1.x) + (-sg) * T.r2.x, (0.0f * T.r0.y + cg * T.r1.y) + (-sg) * T.r2.y,
+               (0.0f * T.r0.z + cg * T.r1.z) + (-sg) * T.r2.z);
+    RT.r2 = v3((0.0f * T.r0.x + sg * T.r1.x) + cg * T.r2.x, (0.0f * T.r0.y + sg * T.r1.y) + cg * T.r2.y,
+               (0.0f * T.r0.z + sg * T.r1.z) + cg * T.r2.z);
+    // G = T^T * RT : G[i][j] = sum_k T[k][i] * RT[k][j]
+    V3 c0 = v3(T.r0.x, T.r1.x, T.r2.x), c1 = v3(T.r0.y, T.r1.y, T.r2.y), c2 = v3(T.r0.z, T.r1.z, T.r2.z);
+    V3 q0 = v3(RT.r0.x, RT.r1.x, RT.r2.x), q1 = v3(RT.r0.y, RT.r1.y, RT.r2.y), q2 = v3(RT.r0.z, RT.r1.z, RT.r2.z);
+    M3 G{v3(dot(c0, q0), dot(c0, q1), dot(c0, q2)), v3(dot(c1, q0), dot(c1, q1), dot(c1, q2)),
+         v3(dot(c2, q0), dot(c2, q1), dot(c2, q2))};
+    return mul(G, dir);
+}
+
+template <int DIM>
+SPH_DEV void transform_standard(const float (&g_)[5], const float (&p_)[5], int edge, int angle, PBox& og, PBox& op) {
+    SBox g = load_sbox<DIM>(g_), p = load_sbox<DIM>(p_);
+    M3 R;
+    V3 df = g.c - p.c;
+    float l1 = (fabsf(df.x) + fabsf(df.y)) + fabsf(df.z);
+    if (l1 > 1e-8f) {  // compute_rotate_matrix_better :264-283
+        V3 look = normalize(g.c + p.c);
+        V3 right = normalize(p.c - g.c);
+        R = M3{look, right, cross(look, right)};
+    } else {  // compute_rotate_matrix(theta_r, phi_r) :286-297
+        float th_r = (g.th + p.th) / 2.0f, ph_r = (g.ph + p.ph) / 2.0f;
+        R = rotate_matrix(sinf(th_r), cosf(th_r), sinf(ph_r), cosf(ph_r));
+    }
+    V3 dg = g.d, dp = p.d;
+    if (DIM == 5) {
+        dg = apply_gamma(g, -g.ga, dg);
+        dp = apply_gamma(p, -p.ga, dp);
+    }
+    V3 cg = mul(R, g.c), cp = mul(R, p.c);
+    dg = mul(R, dg);
+    dp = mul(R, dp);
+    const V3 ez = v3(0.0f, 0.0f, 1.0f), ex = v3(1.0f, 0.0f, 0.0f);
+    auto internal_angle = [&](V3 d) {  // compute_internal_angle :88-108 (+ deg2rad of standardize_rotated_box)
+        if (angle == ANGLE_PROJECT) d.x = 0.0f;
+        float a = fabsf(rad2deg_ref(angle_between(d, ez)));
+        a = a * (d.y > 0.0f ? 1.0f : -1.0f);  // sign_mask(ez, d, ex) == (-d.y < 0)
+        return a * kDeg2Rad;
+    };
+    auto sph_coord = [&](V3 c, float& th, float& ph) {  // compute_spherical_coordinate :175-199
+        ph = rad2deg_ref(angle_between(c, ez)) * kDeg2Rad;
+        V3 cxy = v3(c.x, c.y, 0.0f);
+        float t = rad2deg_ref(angle_between(cxy, ex));
+        t = t * (c.y > 0.0f ? 1.0f : -1.0f);  // sign_mask(ex, cxy, -ez) == (-c.y < 0)
+        th = t * kDeg2Rad;
+    };
+    og.a = internal_angle(dg);
+    op.a = internal_angle(dp);
+    sph_coord(cg, og.x, og.y);
+    sph_coord(cp, op.x, op.y);
+    og.w = edge_length(g.al, edge); og.h = edge_length(g.be, edge);
+    op.w = edge_length(p.al, edge); op.h = edge_length(p.be, edge);
+}
+
+template <int DIM>
+SPH_DEV void transform_efficient(const float (&g_)[5], const float (&p_)[5], int edge, int angle, PBox& og, PBox& op) {
+    SBox g = load_sbox<DIM>(g_), p = load_sbox<DIM>(p_);
+    V3 z = cross(g.c, p.c);
+    V3 s = g.c + p.c;
+    V3 ref = v3(s.x / 2.0f, s.y / 2.0f, s.z / 2.0f);
+    float arc = angle_between(g.c, p.c);
+    V3 dg = g.d, dp = p.d;
+    if (angle == ANGLE_PROJECT) { dg.x = 0.0f; dp.x = 0.0f; }  // :92-93, unrotated-frame quirk kept
+    float ag = angle_between(dg, z) * sign_mask(z, dg, ref);
+    float ap = angle_between(dp, z) * sign_mask(z, dp, ref);
+    if (DIM == 5) { ag = ag - g.ga; ap = ap - p.ga; }
+    og = PBox{0.0f, 0.0f, edge_length(g.al, edge), edge_length(g.be, edge), ag};
+    op = PBox{arc, 0.0f, edge_length(p.al, edge), edge_length(p.be, edge), ap};
+}
+
+SPH_DEV float legacy_angle_aux(float th_box, float ph_box, float th_ref, float ph_ref) {  // sph2pob_legacy.py:120-134
+    float sb = sinf(th_box), cb = cosf(th_box), spb = sinf(ph_box), cpb = cosf(ph_box);
+    float sr = sinf(th_ref), cr = cosf(th_ref), spr = sinf(ph_ref), cpr = cosf(ph_ref);
+    V3 db = v3(cpb * cb, cpb * sb, -spb), dr = v3(cpr * cr, cpr * sr, -spr);
+    float a = fabsf(rad2deg_ref(angle_between(db, dr)));
+    const float hp = (float)(3.141592653589793 / 2);
+    bool sign = ((th_box >= th_ref) && (ph_box < hp)) || ((th_box <= th_ref) && (ph_box > hp));
+    return sign ? a : a * -1.0f;
+}
+SPH_DEV void transform_legacy(const float (&g_)[5], const float (&p_)[5], int edge, PBox& og, PBox& op) {
+    float g0 = g_[0], p0 = p_[0];
+    if (fabsf(g0 - p0) > 180.0f) {  // standardize_spherical_box :236-257
+        g0 = fmodf(g0 + 180.0f, 360.0f);
+        p0 = fmodf(p0 + 180.0f, 360.0f);
+    }
+    const float hpi = (float)(3.141592653589793 / 2);
+    float thg = g0 * kDeg2Rad - kPi, phg = hpi - g_[1] * kDeg2Rad;  // 'convention' :217-234
+    float thp = p0 * kDeg2Rad - kPi, php = hpi - p_[1] * kDeg2Rad;
+    float phi_i = (phg + php) / 2.0f;
+    float phg_ = phg - phi_i, php_ = php - phi_i;
+    float dphi = fabsf(phg - php), dth = fabsf(thg - thp);
+    float s1 = sinf(dphi / 2.0f), s2 = sinf(dth / 2.0f);
+    float L = 2.0f * asinf(sqrtf(s1 * s1 + (cosf(phg) * cosf(php)) * (s2 * s2)));  // :63-66
+    float sl = sinf(L / 2.0f);
+    float q = (sl * sl - s1 * s1) / (cosf(phg_) * cosf(php_));
+    float dth_ = fabsf(2.0f * asinf(sqrtf(q)));  // :70-72 (NaN for q < 0, as in the reference)
+    float sgn = thp > thg ? 1.0f : -1.0f;
+    float mg = g0 * kDeg2Rad, mp = p0 * kDeg2Rad, pg = g_[1] * kDeg2Rad, pp = p_[1] * kDeg2Rad;  // 'math'
+    float mid = (mg + mp) / 2.0f;
+    og.x = 0.0f;       og.y = phg_;
+    op.x = dth_ * sgn; op.y = php_;
+    og.w = edge_length(g_[2] * kDeg2Rad, edge); og.h = edge_length(g_[3] * kDeg2Rad, edge);
+    op.w = edge_length(p_[2] * kDeg2Rad, edge); op.h = edge_length(p_[3] * kDeg2Rad, edge);
+    og.a = legacy_angle_aux(mg, pg, mid, pg) * kDeg2Rad;
+    op.a = legacy_angle_aux(mp, pp, mid, pp) * kDeg2Rad;
+}
+
+template <int VARIANT, int DIM>
+SPH_DEV void transform(const float (&g)[5], const float (&p)[5], int edge, int angle, PBox& og, PBox& op) {
+    if (VARIANT == VARIANT_STANDARD) transform_standard<DIM>(g, p, edge, angle, og, op);
+    else if (VARIANT == VARIANT_EFFICIENT) transform_efficient<DIM>(g, p, edge, angle, og, op);
+    else transform_legacy(g, p, edge, og, op);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Clipped length of the segment P(tau) = (px, py) + tau * (ux, uy), tau in [0, len], inside the
+// axis-aligned box |x| <= hx, |y| <= hy.  iux/iuy are 1/ux, 1/uy (inf when parallel: the products below
+// then evaluate to -inf/+inf "no constraint" or to an empty interval, NaN (0*inf) is dropped by fmin/fmax).
+SPH_DEV float clip_len(float px, float py, float iux, float iuy, float len, float hx, float hy) {
+    float ax = (-hx - px) * iux, bx = (hx - px) * iux;
+    float ay = (-hy - py) * iuy, by = (hy - py) * iuy;
+    float lo = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), 0.0f);
+    float hi = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), len);
+    return fmaxf(hi - lo, 0.0f);
+}
+
+// Twice the boundary integral over the 4 edges of rectangle A (half extents hwa, hha, axes rotated by
+// (c, s) = (cos, sin) of (angle_A - angle_B) in B's frame, centre (pax, pay) in B's frame) clipped to
+// B = [-hwb, hwb] x [-hhb, hhb]; integration origin = B's centre.
+SPH_DEV float edges_inside(float pax, float pay, float c, float s, float ic, float is, float hwa, float hha,
+                           float hwb, float hhb, float wa, float ha, bool with_origin_terms) {
+    float ux = hwa * c, uy = hwa * s;    // +u half extent
+    float vx = -hha * s, vy = hha * c;   // +v half extent
+    // corners k0 = +u+v, k1 = -u+v, k2 = -u-v, k3 = +u-v (counter-clockwise)
+    float k0x = pax + ux + vx, k0y = pay + uy + vy;
+    float k1x = pax - ux + vx, k1y = pay - uy + vy;
+    float k2x = pax - ux - vx, k2y = pay - uy - vy;
+    float k3x = pax + ux - vx, k3y = pay + uy - vy;
+    // edge directions: e0 = -u (k0->k1), e1 = -v (k1->k2), e2 = +u (k2->k3), e3 = +v (k3->k0)
+    float l0 = clip_len(k0x, k0y, -ic, -is, wa, hwb, hhb);
+    float l1 = clip_len(k1x, k1y, is, -ic, ha, hwb, hhb);
+    float l2 = clip_len(k2x, k2y, ic, is, wa, hwb, hhb);
+    float l3 = clip_len(k3x, k3y, -is, ic, ha, hwb, hhb);
+    if (!with_origin_terms) return hha * (l0 + l2) + hwa * (l1 + l3);  // origin = A's own centre
+    float xu = pax * s - pay * c;  // cross(pa, u^)
+    float xv = pax * c + pay * s;  // cross(pa, v^)
+    return (l0 * (hha - xu) + l2 * (hha + xu)) + (l1 * (hwa - xv) + l3 * (hwa + xv));
+}
+
+// Area of the intersection of two rotated rectangles (x, y, w, h, a).
+SPH_DEV float rect_intersection(const PBox& A, const PBox& B) {
+    float sa = sinf(A.a), ca = cosf(A.a), sb = sinf(B.a), cb = cosf(B.a);
+    float dx = B.x - A.x, dy = B.y - A.y;
+    float c = ca * cb + sa * sb;  // cos(aA - aB)
+    float s = sa * cb - ca * sb;  // sin(aA - aB)
+    float ic = 1.0f / c, is = 1.0f / s;
+    float hwa = 0.5f * A.w, hha = 0.5f * A.h, hwb = 0.5f * B.w, hhb = 0.5f * B.h;
+    // A's centre in B's frame; B's centre in A's frame
+    float pax = -(dx * cb + dy * sb), pay = -(dy * cb - dx * sb);
+    float pbx = dx * ca + dy * sa, pby = dy * ca - dx * sa;
+    // A's edges inside B, integrated about B's centre; B's edges inside A, same origin (= B's own centre)
+    float t = edges_inside(pax, pay, c, s, ic, is, hwa, hha, hwb, hhb, A.w, A.h, true) +
+              edges_inside(pbx, pby, c, -s, ic, -is, hwb, hhb, hwa, hha, B.w, B.h, false);
+    return 0.5f * fmaxf(t, 0.0f);
+}
+
+SPH_DEV float planar_iou(const PBox& A, const PBox& B, int mode) {
+    float inter = rect_intersection(A, B);
+    float a1 = A.w * A.h, a2 = B.w * B.h;
+    float base = mode == MODE_IOU ? (a1 + a2 - inter) : a1;
+    return inter / base;
+}
+
+// _sph2pob_iou_auxiliary for one pair — sph_iou_api.py:48-86
+template <int VARIANT, int DIM>
+SPH_DEV float pair_iou(const float (&in1)[5], const float (&in2)[5], int mode, int edge, int angle) {
+    float b1[5], b2[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) { b1[k] = in1[k]; b2[k] = in2[k]; }
+    jitter_spherical<DIM>(b1, b2);
+    PBox p1, p2;
+    transform<VARIANT, DIM>(b1, b2, edge, angle, p1, p2);
+    jitter_rotated(p1, p2);
+    // legacy only: asin(sqrt(q < 0)) is NaN in the reference too; mmcv's kernel then finds no intersection
+    // point (every comparison with NaN is false) and returns 0.
+    if (VARIANT == VARIANT_LEGACY && !(p2.x == p2.x)) return 0.0f;
+    float iou = planar_iou(p1, p2, mode);
+    return fminf(fmaxf(iou, 0.0f), 1.0f);
+}
+
+}  // namespace sph2pob

@@ -1,0 +1,213 @@
+"""GPU parity tests proper: HIP kernels (through the C ABI, via the Python boundary) vs the CPU oracle, the
+committed reference fixtures, and size-independent properties at BASELINE.json's full sizes.
+
+Tolerance model: the north-star bar is |dIoU| <= 1e-5 in fp32.  The reference's own fp32
+arithmetic computes centre distance / edge angles as acos(clamp(dot)) of nearly parallel unit vectors, so two
+faithful fp32 implementations with different libm last-bits (torch-CPU, CUDA, glibc, ocml) differ by more than
+1e-5 on a small, measurable fraction of pairs whose centres are close (14-19 of 1M uniform
+pairs, ~0.5 % of detector-like nearby pairs, against the same code in fp64).  Hence:
+  * well-conditioned strata (uniform benchmark distribution minus the close-centre tail; hand-picked samples):
+    max |d| <= 1e-5 asserted outright;
+  * everywhere: mean |d| < 1e-6 (the reference's own criterion, tests/test_sph_iou_loss.py:34) and the number
+    of >1e-5 outliers against fp64 truth must not exceed what the reference's fp32 arithmetic (the oracle's
+    f32 instantiation) itself produces on the same inputs.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import err_stats, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def S():
+    import sph_retina_amd
+    assert torch.cuda.is_available()
+    return sph_retina_amd
+
+
+FN = {'standard': 'sph2pob_standard_iou', 'efficient': 'sph2pob_efficient_iou', 'legacy': 'sph2pob_legacy_iou'}
+
+
+def hip_iou(S, variant, b1, b2, aligned=True, **kw):
+    t1, t2 = torch.from_numpy(np.ascontiguousarray(b1)).cuda(), torch.from_numpy(np.ascontiguousarray(b2)).cuda()
+    return getattr(S.iou, FN[variant])(t1, t2, is_aligned=aligned, **kw).cpu().numpy()
+
+
+def nearby(b, seed, sigma=(8, 8, 6, 6, 10)):
+    rng = np.random.default_rng(seed)
+    p = b + rng.standard_normal(b.shape).astype(np.float32) * np.asarray(sigma, np.float32)[:b.shape[1]]
+    p[:, 0] %= 360
+    p[:, 1] = p[:, 1].clip(0.5, 179.5)
+    p[:, 2:4] = p[:, 2:4].clip(1, 170)
+    if b.shape[1] == 5:
+        p[:, 4] = p[:, 4].clip(-89, 89)
+    return p.astype(np.float32)
+
+
+def test_samples7_known_answers(S):
+    g = load_golden('samples7')
+    for v in FN:
+        got = hip_iou(S, v, g['b1'], g['b2'])
+        np.testing.assert_allclose(got, g['iou_' + v], atol=1e-5, err_msg=v)
+
+
+@pytest.mark.parametrize('v', list(FN))
+def test_edge_cases(S, oracle, v):
+    g = load_golden('edge_cases')
+    for mode in ('iou', 'iof'):
+        got = hip_iou(S, v, g['b1'], g['b2'], mode=mode)
+        ref = g[f'{mode}_{v}']
+        assert np.isfinite(got).all() and (got >= 0).all() and (got <= 1).all()
+        well = np.array([1, 2, 3, 4, 5, 6, 9, 10])
+        np.testing.assert_allclose(got[well], ref[well], atol=2e-5, err_msg=f'{v}/{mode}')
+        ok = np.isfinite(ref)
+        np.testing.assert_allclose(got[ok], ref[ok], atol=3e-3, err_msg=f'{v}/{mode} (ill-conditioned rows)')
+        orc = oracle.iou_aligned(g['b1'], g['b2'], variant=v, mode=mode, planar='mmcv')
+        # legacy = haversine + asin(sqrt(difference of squares)): its own fp32 noise is ~1e-4 at the theta seam
+        np.testing.assert_allclose(got[well], orc[well], atol=1e-5 if v != 'legacy' else 1e-4)
+
+
+@pytest.mark.parametrize('name,variants', [('uniform_bfov', list(FN)), ('nearby_bfov', list(FN)),
+                                           ('int_bfov', list(FN)), ('uniform_rbfov', ['standard', 'efficient']),
+                                           ('nearby_rbfov', ['standard', 'efficient'])])
+def test_fixtures_from_reference(S, name, variants):
+    g = load_golden(name)
+    for v in variants:
+        got = hip_iou(S, v, g['b1'], g['b2'])
+        ref32, ref64 = g['iou_' + v], g['iou64_' + v]
+        ok = np.isfinite(ref32)
+        s = err_stats(got[ok], ref32[ok])
+        # not further from fp64 truth than the reference's own fp32 run (torch CPU) is
+        mine, theirs = err_stats(got[ok], ref64[ok]), err_stats(ref32[ok], ref64[ok])
+        assert s['mean'] < max(1e-6, 1.5 * theirs['mean']), (name, v, s, theirs)
+        assert s['n5'] <= 0.025 * s['n'], (name, v, s)
+        if name.startswith('uniform'):
+            assert s['max'] < 1e-4, (name, v, s)
+        assert mine['n5'] <= 1.5 * theirs['n5'] + 5, (name, v, mine, theirs)
+        assert mine['mean'] <= 1.5 * theirs['mean'] + 1e-7, (name, v, mine, theirs)
+
+
+def test_options_matrix(S):
+    g = load_golden('options')
+    for key, ref in g.items():
+        if key in ('b1', 'b2', 'r1', 'r2'):
+            continue
+        box, v, edge, ang, mode = key.split('_')
+        b1, b2 = (g['b1'], g['b2']) if box == 'bfov' else (g['r1'], g['r2'])
+        kw = dict(mode=mode, rbb_edge=edge)
+        if v != 'legacy':
+            kw['rbb_angle'] = ang
+        got = hip_iou(S, v, b1, b2, **kw)
+        s = err_stats(got, ref)
+        assert s['mean'] < 2e-6 and s['n4'] <= 3, (key, s)
+
+
+def test_pairwise_fixture_rows_are_first_argument(S):
+    g = load_golden('pairwise')
+    for v in FN:
+        got = hip_iou(S, v, g['b1'], g['b2'], aligned=False)
+        assert got.shape == (7, 11)
+        np.testing.assert_allclose(got, g['iou_' + v], atol=5e-5)
+    for v in ('standard', 'efficient'):
+        got = hip_iou(S, v, g['r1'], g['r2'], aligned=False)
+        np.testing.assert_allclose(got, g['riou_' + v], atol=5e-5)
+
+
+@pytest.mark.parametrize('v,box', [('standard', 'bfov'), ('efficient', 'bfov'), ('legacy', 'bfov'),
+                                   ('standard', 'rbfov'), ('efficient', 'rbfov')])
+@pytest.mark.parametrize('dist', ['uniform', 'nearby'])
+def test_vs_oracle_200k(S, oracle, v, box, dist):
+    n = 200_000
+    b1 = oracle.generate_boxes(n, 101, box=box)
+    b2 = oracle.generate_boxes(n, 202, box=box) if dist == 'uniform' else nearby(b1, 7)
+    got = hip_iou(S, v, b1, b2)
+    ref32 = oracle.iou_aligned(b1, b2, variant=v, planar='mmcv', nthreads=8)
+    truth = oracle.iou_aligned(b1, b2, variant=v, planar='exact', dtype=np.float64, nthreads=8)
+    ok = np.isfinite(ref32) & np.isfinite(truth)
+    assert np.isfinite(got).all() and got.min() >= 0 and got.max() <= 1
+    d = np.sort(np.abs(got[ok].astype(np.float64) - ref32[ok]))
+    trimmed = d[:int(len(d) * 0.9999)]  # drop the 0.01 % largest: jitter-threshold / NaN flips of either side
+    assert trimmed.mean() < 1e-6, (v, box, dist, trimmed.mean())
+    assert np.median(d) <= 1e-7, (v, box, dist, np.median(d))
+    mine, theirs = err_stats(got[ok], truth[ok]), err_stats(ref32[ok], truth[ok])
+    # the reference's fp32 arithmetic (oracle f32) sets the noise floor; the kernel must not add to it
+    assert mine['n5'] <= 1.25 * theirs['n5'] + 10, (v, box, dist, mine, theirs)
+    assert mine['n4'] <= 1.25 * theirs['n4'] + 5, (v, box, dist, mine, theirs)
+    assert np.sort(np.abs(got[ok] - truth[ok]))[:int(len(d) * 0.9999)].mean() <= \
+        1.25 * np.sort(np.abs(ref32[ok] - truth[ok]))[:int(len(d) * 0.9999)].mean() + 1e-7
+    # exact zeros agree (disjoint pairs are exactly 0 in the reference)
+    assert ((got == 0) == (ref32 == 0))[ok].mean() > 0.9999
+    if dist == 'uniform' and v != 'legacy':
+        # the benchmark distribution: the 1e-5 bar holds for all but a handful of close-centre pairs
+        s = err_stats(got[ok], ref32[ok])
+        assert s['max'] < 1e-4 and s['n5'] <= 10, (v, box, dist, s)
+
+
+def test_pairwise_equals_aligned_on_expanded(S, oracle):
+    m, n = 37, 1531
+    b1 = oracle.generate_boxes(m, 5)
+    b2 = oracle.generate_boxes(n, 6)
+    b2[:m] = nearby(b1, 9)
+    for v in FN:
+        pw = hip_iou(S, v, b1, b2, aligned=False)
+        al = hip_iou(S, v, np.repeat(b1, n, axis=0), np.tile(b2, (m, 1)))
+        assert pw.shape == (m, n)
+        np.testing.assert_array_equal(pw.reshape(-1), al)  # same device function -> bit-identical
+
+
+def test_inputs_not_mutated_and_shapes(S):
+    # reference tests/test_all_ious.py:322-332
+    a = torch.rand(1000, 4, device='cuda') * 90 + 1
+    b = a + 1.0
+    b[::7] = a[::7]  # identical rows trigger the spherical jitter path
+    a0, b0 = a.clone(), b.clone()
+    out = S.sph2pob_standard_iou(a, b, is_aligned=True)
+    assert out.shape == (1000,) and out.dtype == torch.float32 and out.device == a.device
+    assert torch.equal(a, a0) and torch.equal(b, b0)
+    out = S.sph2pob_efficient_iou(a[:5], b[:9])
+    assert out.shape == (5, 9)
+    assert S.sph2pob_standard_iou(a[:0], b[:3]).shape == (0, 3)
+    assert S.sph2pob_standard_iou(a[:0], b[:0], is_aligned=True).shape == (0, 1)
+    with pytest.raises(AssertionError):
+        S.sph2pob_standard_iou(a, b, mode='giou')
+    with pytest.raises(AssertionError):
+        S.sph2pob_standard_iou(a, b, rbb_edge='secant')
+    with pytest.raises(ValueError):
+        S.sph2pob_legacy_iou(torch.rand(3, 5, device='cuda'), torch.rand(3, 5, device='cuda'))
+    # non-contiguous and fp64 inputs are accepted (converted on the fly), extra score column is dropped
+    calc = S.SphOverlaps2D(backend='sph2pob_standard_iou', box_version=4)
+    with_scores = torch.cat([a, torch.rand(1000, 1, device='cuda')], 1)
+    np.testing.assert_array_equal(calc(with_scores[:64], b[:128]).cpu().numpy(),
+                                  S.sph2pob_standard_iou(a[:64], b[:128]).cpu().numpy())
+    assert S.sph2pob_standard_iou(a.double(), b.double(), is_aligned=True).dtype == torch.float64
+
+
+def test_full_size_properties_1m(S, oracle):
+    """BASELINE config 2 size (1,000,000 BFoV pairs): size-independent properties."""
+    n = 1_000_000
+    b1 = torch.from_numpy(oracle.generate_boxes(n, 0)).cuda()
+    b2 = torch.from_numpy(oracle.generate_boxes(n, 1)).cuda()
+    iou = S.sph2pob_efficient_iou(b1, b2, is_aligned=True)
+    assert iou.shape == (n,) and bool(torch.isfinite(iou).all())
+    assert float(iou.min()) >= 0 and float(iou.max()) <= 1
+    frac = float((iou > 0).float().mean())
+    assert 0.24 < frac < 0.28, frac  # 26 % of uniform pairs overlap
+    # role swap: IoU is symmetric up to the (asymmetric) jitter constants
+    sw = S.sph2pob_efficient_iou(b2, b1, is_aligned=True)
+    assert float((iou - sw).abs().max()) < 5e-3 and float((iou - sw).abs().mean()) < 1e-6
+    # standard and efficient are the same function of the pair (rigid planar motion)
+    st = S.sph2pob_standard_iou(b1, b2, is_aligned=True)
+    d = (iou - st).abs()
+    assert float(d.mean()) < 1e-6 and int((d > 1e-4).sum()) <= 20
+    # IoU(x, x) ~ 1 (jitter keeps it just below), iof >= iou
+    same = S.sph2pob_standard_iou(b1[:100000], b1[:100000].clone(), is_aligned=True)
+    assert float(same.min()) > 0.9 and float(same.max()) <= 1.0
+    iof = S.sph2pob_efficient_iou(b1, b2, mode='iof', is_aligned=True)
+    assert bool((iof >= iou - 1e-6).all())
+    # a random 20k sample against the oracle
+    idx = torch.randperm(n, device='cuda')[:20000]
+    ref = oracle.iou_aligned(b1[idx].cpu().numpy(), b2[idx].cpu().numpy(), variant='efficient', planar='mmcv')
+    assert np.abs(iou[idx].cpu().numpy() - ref).mean() < 1e-6
