@@ -74,6 +74,38 @@ int sph2pob_iou_pairwise_f32(const float* b1, int64_t m, const float* b2, int64_
 int sph2pob_transform_f32(const float* b1, const float* b2, float* planar1, float* planar2, int64_t n,
                           int box_dim, int variant, int edge, int angle, int jitter, void* stream);
 
+/*
+ * Sph2PobIoULoss element values: loss[i] = scale * w_i * L(pred[i], target[i]), L = 1 - IoU | GIoU | DIoU | CIoU
+ * form; scale carries loss_weight (sph2pob_iou_loss.py:49).
+ * Replaces Sph2PobTransfrom.new_forward (sphdet/losses/sph2pob_transform.py:24-35: clone, spherical jitter,
+ * sph2pob_standard(..., 'rad'), rotated jitter) + obb_iou_loss (sphdet/losses/sph2pob_iou_loss.py:104-196, whose
+ * IoU is mmcv diff_iou_rotated_2d, :122) + the element-weight step of weight_reduce_loss
+ * (mmdet/models/losses/utils.py:44-45).  weight: NULL, (n) [weight_dim 1] or (n, box_dim) [weight_dim box_dim:
+ * the per-box mean is taken as OBBIoULoss.forward does, sph2pob_iou_loss.py:43-48].  iou (optional, may be NULL)
+ * receives the clamped planar IoU.  eps = the loss's eps (default 1e-6, sph2pob_iou_loss.py:17).
+ */
+int sph2pob_loss_fwd_f32(const float* pred, const float* target, const float* weight, int weight_dim, float scale,
+                         float* loss, float* iou, int64_t n, int box_dim, int loss_mode, float eps, void* stream);
+
+/*
+ * Adjoint of the above w.r.t. the spherical inputs (degrees): grad_pred[i,:] = g_i * dL_i/dpred[i,:], likewise
+ * grad_target (optional, may be NULL), with g_i = grad_out[i * grad_stride] * scale * w_i  (grad_stride 0 =
+ * one scalar upstream gradient, e.g. of a 'mean'/'sum' reduced loss; 1 = per element, reduction 'none').
+ * Replaces torch autograd through the ~150 ops the reference records for this loss.  Recomputes the forward in
+ * registers: reads only pred, target, weight and grad_out.
+ */
+int sph2pob_loss_bwd_f32(const float* pred, const float* target, const float* weight, int weight_dim,
+                         const float* grad_out, int grad_stride, float scale, float* grad_pred, float* grad_target,
+                         int64_t n, int box_dim, int loss_mode, float eps, void* stream);
+
+/*
+ * out[0] = scale * sum(x[0..n)) — deterministic two-pass tree (bitwise reproducible, no float atomics); the
+ * reduction step of weight_reduce_loss (mmdet/models/losses/utils.py:47-55).  workspace: device buffer of at
+ * least sph2pob_sum_workspace_floats() floats.
+ */
+int sph2pob_sum_workspace_floats(void);
+int sph2pob_sum_f32(const float* x, int64_t n, float scale, float* out, float* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

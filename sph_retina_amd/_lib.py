@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 LIB_DIR = os.path.join(_HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libsph2pob_hip.so')
 SOURCES = ['sph2pob_kernels.hip']
-HEADERS = ['sph2pob_device.hpp', os.path.join('..', '..', 'include', 'sph2pob_hip.h')]
+HEADERS = ['sph2pob_device.hpp', 'sph2pob_loss.hpp', os.path.join('..', '..', 'include', 'sph2pob_hip.h')]
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off']
 
 _c_f32p = ctypes.c_void_p
@@ -31,6 +31,13 @@ SIGNATURES = {
                                  ctypes.c_void_p],
     'sph2pob_transform_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _int, _int, _int, _int,
                               ctypes.c_void_p],
+    'sph2pob_loss_fwd_f32': [_c_f32p, _c_f32p, _c_f32p, _int, ctypes.c_float, _c_f32p, _c_f32p, _i64, _int, _int,
+                             ctypes.c_float,
+                             ctypes.c_void_p],
+    'sph2pob_loss_bwd_f32': [_c_f32p, _c_f32p, _c_f32p, _int, _c_f32p, _int, ctypes.c_float, _c_f32p, _c_f32p, _i64,
+                             _int, _int, ctypes.c_float, ctypes.c_void_p],
+    'sph2pob_sum_workspace_floats': [],
+    'sph2pob_sum_f32': [_c_f32p, _i64, ctypes.c_float, _c_f32p, _c_f32p, ctypes.c_void_p],
 }
 _RESTYPES = {'sph2pob_target_arch': ctypes.c_char_p, 'sph2pob_error_string': ctypes.c_char_p}
 

@@ -29,7 +29,7 @@ enum : int { ANGLE_EQUATOR = 0, ANGLE_PROJECT = 1 };
 struct PBox { float x, y, w, h, a; };
 struct V3 { float x, y, z; };
 
-#define SPH_DEV __device__ __forceinline__
+#define SPH_DEV __host__ __device__ __forceinline__
 
 // ---- constants, rounded to fp32 exactly like the reference's python-double -> float32 casts ----
 constexpr float kDeg2Rad = 0.017453292519943295f;       // torch.deg2rad scalar

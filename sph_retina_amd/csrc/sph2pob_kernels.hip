@@ -4,6 +4,7 @@
 
 #include "../../include/sph2pob_hip.h"
 #include "sph2pob_device.hpp"
+#include "sph2pob_loss.hpp"
 
 namespace {
 
@@ -69,6 +70,93 @@ __global__ __launch_bounds__(kBlock) void transform_kernel(const float* __restri
     float* q2 = o2 + i * 5;
     q1[0] = p1.x; q1[1] = p1.y; q1[2] = p1.w; q1[3] = p1.h; q1[4] = p1.a;
     q2[0] = p2.x; q2[1] = p2.y; q2[2] = p2.w; q2[3] = p2.h; q2[4] = p2.a;
+}
+
+
+// ---- loss: per-element weight = mean over weight_dim columns (reference: sph2pob_transform.py:32-34 widens a
+// (n,4) weight with its own mean, OBBIoULoss.forward then takes weight.mean(-1): sph2pob_iou_loss.py:48) ----
+template <int DIM>
+__device__ __forceinline__ float element_weight(const float* __restrict__ w, int wd, int64_t i) {
+    if (!w) return 1.0f;
+    if (wd == 1) return w[i];
+    float s = 0.0f;
+    for (int k = 0; k < wd; k++) s += w[i * wd + k];
+    if (DIM == 4 && wd == 4) return (s + s / 4.0f) / 5.0f;
+    return s / (float)wd;
+}
+
+template <int DIM>
+__global__ __launch_bounds__(kBlock) void loss_fwd_kernel(const float* __restrict__ pred,
+                                                         const float* __restrict__ target,
+                                                         const float* __restrict__ weight, int wd,
+                                                         float scale, float* __restrict__ loss,
+                                                         float* __restrict__ iou, int64_t n, int loss_mode,
+                                                         float eps) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float x[5], y[5], gx[5], gy[5], io;
+    load_box<DIM>(pred, i, x);
+    load_box<DIM>(target, i, y);
+    float l = pair_loss<DIM, false>(x, y, loss_mode, eps, &io, gx, gy);
+    loss[i] = l * (scale * element_weight<DIM>(weight, wd, i));
+    if (iou) iou[i] = io;
+}
+
+template <int DIM>
+__global__ __launch_bounds__(kBlock) void loss_bwd_kernel(const float* __restrict__ pred,
+                                                         const float* __restrict__ target,
+                                                         const float* __restrict__ weight, int wd,
+                                                         const float* __restrict__ grad_out, int grad_stride,
+                                                         float scale, float* __restrict__ gpred,
+                                                         float* __restrict__ gtarget, int64_t n, int loss_mode,
+                                                         float eps) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float x[5], y[5], gx[5], gy[5];
+    load_box<DIM>(pred, i, x);
+    load_box<DIM>(target, i, y);
+    pair_loss<DIM, true>(x, y, loss_mode, eps, nullptr, gx, gy);
+    float g = grad_out[i * grad_stride] * scale * element_weight<DIM>(weight, wd, i);
+    if (DIM == 4) {
+        reinterpret_cast<float4*>(gpred)[i] = make_float4(g * gx[0], g * gx[1], g * gx[2], g * gx[3]);
+        if (gtarget) reinterpret_cast<float4*>(gtarget)[i] = make_float4(g * gy[0], g * gy[1], g * gy[2], g * gy[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 5; k++) gpred[i * 5 + k] = g * gx[k];
+        if (gtarget) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) gtarget[i * 5 + k] = g * gy[k];
+        }
+    }
+}
+
+// ---- deterministic two-pass sum (bitwise reproducible losses; no float atomics) ----
+constexpr int kSumBlocks = 1024;
+__device__ __forceinline__ float block_sum(float v) {
+    __shared__ float sm[kBlock / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = 0.0f;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < kBlock / 64; k++) r += sm[k];
+    }
+    return r;
+}
+__global__ __launch_bounds__(kBlock) void sum_pass1(const float* __restrict__ x, int64_t n, float* __restrict__ ws) {
+    float acc = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) acc += x[i];
+    float r = block_sum(acc);
+    if (threadIdx.x == 0) ws[blockIdx.x] = r;
+}
+__global__ __launch_bounds__(kBlock) void sum_pass2(const float* __restrict__ ws, int nb, float scale,
+                                                   float* __restrict__ out) {
+    float acc = 0.0f;
+    for (int i = threadIdx.x; i < nb; i += kBlock) acc += ws[i];
+    float r = block_sum(acc);
+    if (threadIdx.x == 0) out[0] = r * scale;
 }
 
 int check_common(int box_dim, int variant, int edge, int angle) {
@@ -175,6 +263,55 @@ int sph2pob_transform_f32(const float* b1, const float* b2, float* planar1, floa
     if (!b1 || !b2 || !planar1 || !planar2) return SPH2POB_ERR_NULL;
     return dispatch(variant, box_dim,
                     TransformLaunch{b1, b2, planar1, planar2, n, edge, angle, jitter, (hipStream_t)stream});
+}
+
+int sph2pob_loss_fwd_f32(const float* pred, const float* target, const float* weight, int weight_dim, float scale,
+                         float* loss, float* iou, int64_t n, int box_dim, int loss_mode, float eps, void* stream) {
+    if (box_dim != 4 && box_dim != 5) return SPH2POB_ERR_DIM;
+    if (loss_mode < 0 || loss_mode > 3) return SPH2POB_ERR_OPTION;
+    if (weight && weight_dim != 1 && weight_dim != box_dim) return SPH2POB_ERR_OPTION;
+    if (n < 0 || n > kMaxElems) return SPH2POB_ERR_SIZE;
+    if (n == 0) return SPH2POB_OK;
+    if (!pred || !target || !loss) return SPH2POB_ERR_NULL;
+    dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+    hipStream_t s = (hipStream_t)stream;
+    if (box_dim == 4)
+        hipLaunchKernelGGL((loss_fwd_kernel<4>), grid, dim3(kBlock), 0, s, pred, target, weight, weight_dim, scale, loss, iou, n, loss_mode, eps);
+    else
+        hipLaunchKernelGGL((loss_fwd_kernel<5>), grid, dim3(kBlock), 0, s, pred, target, weight, weight_dim, scale, loss, iou, n, loss_mode, eps);
+    return launch_status();
+}
+
+int sph2pob_loss_bwd_f32(const float* pred, const float* target, const float* weight, int weight_dim,
+                         const float* grad_out, int grad_stride, float scale, float* grad_pred, float* grad_target,
+                         int64_t n, int box_dim, int loss_mode, float eps, void* stream) {
+    if (box_dim != 4 && box_dim != 5) return SPH2POB_ERR_DIM;
+    if (loss_mode < 0 || loss_mode > 3 || (grad_stride != 0 && grad_stride != 1)) return SPH2POB_ERR_OPTION;
+    if (weight && weight_dim != 1 && weight_dim != box_dim) return SPH2POB_ERR_OPTION;
+    if (n < 0 || n > kMaxElems) return SPH2POB_ERR_SIZE;
+    if (n == 0) return SPH2POB_OK;
+    if (!pred || !target || !grad_out || !grad_pred) return SPH2POB_ERR_NULL;
+    dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+    hipStream_t s = (hipStream_t)stream;
+    if (box_dim == 4)
+        hipLaunchKernelGGL((loss_bwd_kernel<4>), grid, dim3(kBlock), 0, s, pred, target, weight, weight_dim, grad_out, grad_stride, scale, grad_pred, grad_target, n, loss_mode, eps);
+    else
+        hipLaunchKernelGGL((loss_bwd_kernel<5>), grid, dim3(kBlock), 0, s, pred, target, weight, weight_dim, grad_out, grad_stride, scale, grad_pred, grad_target, n, loss_mode, eps);
+    return launch_status();
+}
+
+int sph2pob_sum_workspace_floats(void) { return kSumBlocks; }
+
+int sph2pob_sum_f32(const float* x, int64_t n, float scale, float* out, float* workspace, void* stream) {
+    if (n < 0 || n > kMaxElems) return SPH2POB_ERR_SIZE;
+    if (!out || !workspace || (n > 0 && !x)) return SPH2POB_ERR_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    int nb = (int)((n + kBlock - 1) / kBlock);
+    if (nb > kSumBlocks) nb = kSumBlocks;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(sum_pass1, dim3(nb), dim3(kBlock), 0, s, x, n, workspace);
+    hipLaunchKernelGGL(sum_pass2, dim3(1), dim3(kBlock), 0, s, workspace, nb, scale, out);
+    return launch_status();
 }
 
 }  // extern "C"

@@ -1,0 +1,4 @@
+from .sph2pob_iou_loss import OBBIoULoss, Sph2PobIoULoss, SphIoULoss, sph2pob_iou_loss  # noqa: F401
+from .sph2pob_transform import Sph2PobTransfrom  # noqa: F401
+
+__all__ = ['Sph2PobIoULoss', 'SphIoULoss', 'OBBIoULoss', 'Sph2PobTransfrom', 'sph2pob_iou_loss']

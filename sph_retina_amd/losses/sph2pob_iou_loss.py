@@ -1,0 +1,124 @@
+"""`Sph2PobIoULoss` — the reference's registered IoU-family regression loss for spherical boxes
+(sphdet/losses/sph2pob_iou_loss.py:218-220 = OBBIoULoss (:16-58) wrapped by Sph2PobTransfrom), fused end to end:
+
+    forward : ONE kernel  (jitter -> sph2pob_standard -> jitter -> rotated IoU -> IoU|GIoU|DIoU|CIoU -> x weight)
+              + a deterministic two-pass sum for 'mean' / 'sum'
+    backward: ONE kernel  (recomputes the forward in registers, closed-form adjoint down to the spherical inputs)
+
+Constructor / call signature, assertion behaviour, weight handling ((n,) or (n, box_dim) weights averaged per box,
+sph2pob_iou_loss.py:43-48), `avg_factor` semantics (mmdet/models/losses/utils.py:47-58) and `reduction_override`
+follow the reference.  Difference: the reference's all-zero-weight shortcut (:36-39) needs a device->host sync
+(`torch.any`); here zero weights simply produce a zero loss with zero gradients on the normal path.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .. import _torch_glue as G
+from ..registry import LOSSES
+
+LOSS_MODES = {'iou': 0, 'giou': 1, 'diou': 2, 'ciou': 3}
+_F32_EPS = float(torch.finfo(torch.float32).eps)
+
+
+class _Sph2PobLossFunction(torch.autograd.Function):
+    """(pred, target[, weight]) -> weighted element losses (reduce=False) or their sum (reduce=True)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, weight, mode_c, eps, scale, reduce):
+        G.require_hip(pred, target)
+        n, dim = pred.shape
+        p, t = G.as_f32(pred.detach()), G.as_f32(target.detach())
+        w = G.as_f32(weight.detach()) if weight is not None else None
+        wd = 0 if w is None else (1 if w.dim() == 1 else w.size(1))
+        dev = p.device
+        elem = torch.empty((n,), dtype=torch.float32, device=dev)
+        if n:
+            G.call('sph2pob_loss_fwd_f32', dev, G.ptr(p), G.ptr(t), G.ptr(w), wd, ctypes.c_float(scale), G.ptr(elem),
+                   ctypes.c_void_p(0), ctypes.c_int64(n), dim, mode_c, ctypes.c_float(eps), G.stream_of(p))
+        ctx.save_for_backward(p, t, w)
+        ctx.meta = (mode_c, eps, scale, reduce, wd, pred.dtype, target.dtype)
+        if not reduce:
+            return elem
+        out = torch.zeros((), dtype=torch.float32, device=dev)
+        if n:
+            ws = torch.empty((_lib.lib().sph2pob_sum_workspace_floats(),), dtype=torch.float32, device=dev)
+            G.call('sph2pob_sum_f32', dev, G.ptr(elem), ctypes.c_int64(n), ctypes.c_float(1.0), G.ptr(out), G.ptr(ws),
+                   G.stream_of(p))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        p, t, w = ctx.saved_tensors
+        mode_c, eps, scale, reduce, wd, pdt, tdt = ctx.meta
+        n, dim = p.shape
+        need_p, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g = G.as_f32(grad_out)
+        gp = torch.empty_like(p)
+        gt = torch.empty_like(t) if need_t else None
+        if n:
+            G.call('sph2pob_loss_bwd_f32', p.device, G.ptr(p), G.ptr(t), G.ptr(w), wd, G.ptr(g), 0 if reduce else 1,
+                   ctypes.c_float(scale), G.ptr(gp), G.ptr(gt), ctypes.c_int64(n), dim, mode_c, ctypes.c_float(eps),
+                   G.stream_of(p))
+        return (gp.to(pdt) if need_p else None), (gt.to(tdt) if need_t else None), None, None, None, None, None
+
+
+def sph2pob_iou_loss(pred, target, weight=None, mode='iou', eps=1e-6, reduction='mean', avg_factor=None,
+                     loss_weight=1.0):
+    """Functional form: loss_weight * weight_reduce_loss(obb_iou_loss(sph2pob(pred, target)), weight, ...)."""
+    assert mode in LOSS_MODES
+    if pred.dim() != 2 or pred.shape != target.shape or pred.size(1) not in (4, 5):
+        raise ValueError(f'pred/target must both be (n, 4) or (n, 5), got {tuple(pred.shape)}, {tuple(target.shape)}')
+    if avg_factor is not None and reduction == 'sum':
+        raise ValueError('avg_factor can not be used with reduction="sum"')
+    n = pred.size(0)
+    if reduction == 'none':
+        return _Sph2PobLossFunction.apply(pred, target, weight, LOSS_MODES[mode], float(eps), float(loss_weight), False)
+    assert reduction in ('mean', 'sum')
+    total = _Sph2PobLossFunction.apply(pred, target, weight, LOSS_MODES[mode], float(eps), float(loss_weight), True)
+    if reduction == 'sum':
+        return total
+    if avg_factor is None:
+        return total / n if n else total * float('nan')  # torch: mean of an empty tensor is nan
+    return total / (avg_factor + _F32_EPS)
+
+
+class OBBIoULoss(nn.Module):
+    """Same constructor / forward signature as the reference's OBBIoULoss (sph2pob_iou_loss.py:16-58); `forward`
+    takes SPHERICAL boxes (the Sph2Pob transform is inside the fused kernels)."""
+
+    def __init__(self, mode='iou', eps=1e-6, reduction='mean', loss_weight=1.0):
+        super().__init__()
+        assert mode in ['iou', 'giou', 'diou', 'ciou']
+        self.mode = mode
+        self.eps = eps
+        self.reduction = reduction
+        self.loss_weight = loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None, **kwargs):
+        assert reduction_override in (None, 'none', 'mean', 'sum')
+        reduction = reduction_override if reduction_override else self.reduction
+        if weight is not None and weight.dim() > 1:
+            assert weight.shape == pred.shape
+        return sph2pob_iou_loss(pred, target, weight, mode=self.mode, eps=self.eps, reduction=reduction,
+                                avg_factor=avg_factor, loss_weight=self.loss_weight)
+
+
+@LOSSES.register_module()
+class Sph2PobIoULoss(OBBIoULoss):
+    """dict(type='Sph2PobIoULoss', mode='ciou', loss_weight=1.0) — reference sph2pob_iou_loss.py:218-235."""
+    pass
+
+
+@LOSSES.register_module()
+class SphIoULoss(OBBIoULoss):
+    """The reference's SphIoULoss (sph2pob_iou_loss.py:238-292) cannot be constructed at HEAD (its default
+    iou_calculator is rejected by its own assert) and only implements mode='iou' through the Sph2Pob IoU.  Served
+    here by the same fused kernels; `iou_calculator` accepts both spellings of the Sph2Pob backend."""
+
+    def __init__(self, mode='iou', iou_calculator='sph2pob_standard_iou', eps=1e-6, reduction='mean', loss_weight=1.0):
+        assert iou_calculator in ['sph2pob_standard', 'sph2pob_standard_iou'], \
+            "only the Sph2Pob calculator is on the MI355X hot path ('sph'/'fov' closed forms: SURVEY §8f-4)"
+        super().__init__(mode=mode, eps=eps, reduction=reduction, loss_weight=loss_weight)

@@ -1,0 +1,53 @@
+// TEST INFRASTRUCTURE (never shipped, never loaded by the product): compiles the product's device math
+// (sph_retina_amd/csrc/*.hpp, __host__ __device__) for the HOST so that the hand-derived loss adjoint and the
+// boundary-integral rectangle intersection can be unit-tested and sanitised on machines without a GPU.
+#include <stdint.h>
+#include "../../sph_retina_amd/csrc/sph2pob_device.hpp"
+#include "../../sph_retina_amd/csrc/sph2pob_loss.hpp"
+
+using namespace sph2pob;
+
+template <int DIM>
+static void loss_loop(const float* pred, const float* target, int64_t n, int mode, float eps, float* loss, float* iou,
+                      float* gp, float* gt) {
+    for (int64_t i = 0; i < n; i++) {
+        float x[5] = {0, 0, 0, 0, 0}, y[5] = {0, 0, 0, 0, 0}, gx[5], gy[5], io;
+        for (int k = 0; k < DIM; k++) { x[k] = pred[i * DIM + k]; y[k] = target[i * DIM + k]; }
+        loss[i] = pair_loss<DIM, true>(x, y, mode, eps, &io, gx, gy);
+        iou[i] = io;
+        for (int k = 0; k < DIM; k++) { gp[i * DIM + k] = gx[k]; gt[i * DIM + k] = gy[k]; }
+    }
+}
+
+template <int V, int DIM>
+static void iou_loop(const float* b1, const float* b2, int64_t n, int mode, int edge, int angle, float* out) {
+    for (int64_t i = 0; i < n; i++) {
+        float x[5] = {0, 0, 0, 0, 0}, y[5] = {0, 0, 0, 0, 0};
+        for (int k = 0; k < DIM; k++) { x[k] = b1[i * DIM + k]; y[k] = b2[i * DIM + k]; }
+        out[i] = pair_iou<V, DIM>(x, y, mode, edge, angle);
+    }
+}
+
+extern "C" {
+int harness_loss(const float* pred, const float* target, int64_t n, int dim, int mode, float eps, float* loss,
+                 float* iou, float* gp, float* gt) {
+    if (dim == 4) loss_loop<4>(pred, target, n, mode, eps, loss, iou, gp, gt);
+    else loss_loop<5>(pred, target, n, mode, eps, loss, iou, gp, gt);
+    return 0;
+}
+int harness_iou(const float* b1, const float* b2, int64_t n, int dim, int variant, int mode, int edge, int angle,
+                float* out) {
+    if (variant == 0) { if (dim == 4) iou_loop<0, 4>(b1, b2, n, mode, edge, angle, out); else iou_loop<0, 5>(b1, b2, n, mode, edge, angle, out); }
+    else if (variant == 1) { if (dim == 4) iou_loop<1, 4>(b1, b2, n, mode, edge, angle, out); else iou_loop<1, 5>(b1, b2, n, mode, edge, angle, out); }
+    else iou_loop<2, 4>(b1, b2, n, mode, edge, angle, out);
+    return 0;
+}
+int harness_planar_iou(const float* p1, const float* p2, int64_t n, int mode, float* out) {
+    for (int64_t i = 0; i < n; i++) {
+        PBox A{p1[i * 5], p1[i * 5 + 1], p1[i * 5 + 2], p1[i * 5 + 3], p1[i * 5 + 4]};
+        PBox B{p2[i * 5], p2[i * 5 + 1], p2[i * 5 + 2], p2[i * 5 + 3], p2[i * 5 + 4]};
+        out[i] = planar_iou(A, B, mode);
+    }
+    return 0;
+}
+}

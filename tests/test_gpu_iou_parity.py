@@ -138,8 +138,11 @@ def test_vs_oracle_200k(S, oracle, v, box, dist):
     assert mine['n4'] <= 1.25 * theirs['n4'] + 5, (v, box, dist, mine, theirs)
     assert np.sort(np.abs(got[ok] - truth[ok]))[:int(len(d) * 0.9999)].mean() <= \
         1.25 * np.sort(np.abs(ref32[ok] - truth[ok]))[:int(len(d) * 0.9999)].mean() + 1e-7
-    # exact zeros agree (disjoint pairs are exactly 0 in the reference)
-    assert ((got == 0) == (ref32 == 0))[ok].mean() > 0.9999
+    # exact zeros agree (disjoint pairs are exactly 0 in the reference); the only disagreements are slivers that
+    # mmcv's hull drops through its absolute tolerances (points within 1e-4 of each other count as one point)
+    dis = ((got == 0) != (ref32 == 0)) & ok
+    assert dis.mean() < 5e-4 and (not dis.any() or np.maximum(got, ref32)[dis].max() < 1e-4), \
+        (v, box, dist, dis.sum(), np.maximum(got, ref32)[dis].max())
     if dist == 'uniform' and v != 'legacy':
         # the benchmark distribution: the 1e-5 bar holds for all but a handful of close-centre pairs
         # (a jitter-threshold flip between two fp32 realisations shows up as one ~1e-3 outlier per ~1e6 pairs)

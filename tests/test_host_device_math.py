@@ -1,0 +1,82 @@
+"""CPU: the product's device math (sph_retina_amd/csrc/*.hpp) compiled for the host by tests/host_harness —
+checks the algebra the GPU kernels run (boundary-integral intersection, transforms, hand-derived loss adjoint)
+against the oracle and the reference fixtures without needing a GPU."""
+import numpy as np
+import pytest
+
+from conftest import err_stats, load_golden
+
+
+def test_boundary_integral_intersection_vs_exact_clip(host_harness, oracle):
+    g = load_golden('planar')
+    got = host_harness.planar_iou(g['p1'], g['p2'])
+    truth = oracle.planar_iou(g['p1'], g['p2'], planar='exact', dtype=np.float64)
+    s = err_stats(got, truth)
+    assert s['max'] < 5e-6 and s['mean'] < 2e-7, s
+    assert ((got == 0) == (truth == 0)).mean() > 0.999
+    # disjoint / contained after a 90-degree turn / exactly parallel edges (rcp(0) = inf path) / contained / cross.
+    # Exactly COINCIDENT edges are outside the function's domain: jiter_rotated_bboxes always runs first and
+    # separates sizes by 1.2e-4 and angles by >= 1.2e-3 (sph_iou_api.py:222-242).
+    a = np.array([[0, 0, 2, 1, 0.3], [0, 0, 2, 1, 0.0], [0, 0, 2, 1, 0.0], [0, 0, 4, 4, 0.0], [0, 0, 2, 1, 0.0]],
+                 np.float32)
+    b = np.array([[5, 5, 1, 1, 1.0], [0, 0, 1.2, 2.2, np.pi / 2], [0.5, 0.1, 2, 1.4, 0.0], [0.2, -0.1, 1, 1, 0.7],
+                  [0, 0, 1, 2, 0.0]], np.float32)
+    np.testing.assert_allclose(host_harness.planar_iou(a, b), [0.0, 2 / 2.64, 1.5 / 3.3, 1.0 / 16.0, 1.0 / 3.0],
+                               atol=2e-6)
+    np.testing.assert_allclose(host_harness.planar_iou(b, a, mode='iof')[3], 1.0, atol=2e-6)
+
+
+@pytest.mark.parametrize('name,variants', [('uniform_bfov', ['standard', 'efficient', 'legacy']),
+                                           ('nearby_rbfov', ['standard', 'efficient']),
+                                           ('int_bfov', ['standard', 'efficient', 'legacy'])])
+def test_device_iou_pipeline_on_host_vs_reference(host_harness, name, variants):
+    g = load_golden(name)
+    for v in variants:
+        got = host_harness.iou(g['b1'], g['b2'], variant=v)
+        ref32, ref64 = g['iou_' + v], g['iou64_' + v]
+        s, theirs = err_stats(got, ref32), err_stats(ref32, ref64)
+        assert s['mean'] < max(1e-6, 1.5 * theirs['mean']), (name, v, s)
+        assert s['n5'] <= max(0.025 * s['n'], 1.5 * theirs['n5']), (name, v, s)
+
+
+def test_device_options_on_host(host_harness):
+    g = load_golden('options')
+    for key, ref in g.items():
+        if key in ('b1', 'b2', 'r1', 'r2'):
+            continue
+        box, v, edge, ang, mode = key.split('_')
+        b1, b2 = (g['b1'], g['b2']) if box == 'bfov' else (g['r1'], g['r2'])
+        got = host_harness.iou(b1, b2, variant=v, mode=mode, edge=edge, angle=ang)
+        s = err_stats(got, ref)
+        assert s['mean'] < 2e-6 and s['n4'] <= 3, (key, s)
+
+
+@pytest.mark.parametrize('box', ['bfov', 'rbfov'])
+@pytest.mark.parametrize('mode', ['iou', 'giou', 'diou', 'ciou'])
+def test_loss_adjoint_vs_reference_autograd(host_harness, box, mode):
+    """Hand-derived backward vs the reference's torch autograd (fixtures from the unmodified reference)."""
+    g = load_golden('loss_' + box)
+    loss, iou, gp, gt = host_harness.loss(g['pred'], g['target'], mode)
+    s = err_stats(loss, g['loss_' + mode])
+    assert s['mean'] < 2e-6 and s['n4'] <= 2, s
+    for mine, ref in ((gp, g['gpred_' + mode]), (gt, g['gtarget_' + mode])):
+        d = np.abs(mine - ref)
+        scale = np.abs(ref).max()
+        assert np.median(d) < 1e-6 * scale, (np.median(d), scale)
+        assert np.quantile(d, 0.99) < 2e-4 * scale, (np.quantile(d, 0.99), scale)
+        assert d.max() < 5e-3 * scale, (d.max(), scale)
+
+
+@pytest.mark.parametrize('box', ['bfov', 'rbfov'])
+def test_loss_adjoint_vs_fp64_finite_differences(host_harness, oracle, box):
+    """Independent check: central finite differences of the f64 oracle (no shared code with the kernels)."""
+    g = load_golden('loss_' + box)
+    sl = slice(0, 150)
+    for mode in ('iou', 'giou', 'ciou'):
+        _, _, gp, gt = host_harness.loss(g['pred'][sl], g['target'][sl], mode)
+        fp, ft = oracle.loss_grad_fd(g['pred'][sl], g['target'][sl], mode=mode)
+        for mine, fd in ((gp, fp), (gt, ft)):
+            d = np.abs(mine - fd)
+            scale = np.abs(fd).max()
+            assert np.median(d) < 2e-4 * scale, (mode, np.median(d), scale)
+            assert (d > 0.05 * scale).mean() < 0.03, (mode, (d > 0.05 * scale).mean())
