@@ -106,6 +106,20 @@ int sph2pob_loss_bwd_f32(const float* pred, const float* target, const float* we
 int sph2pob_sum_workspace_floats(void);
 int sph2pob_sum_f32(const float* x, int64_t n, float scale, float* out, float* workspace, void* stream);
 
+/*
+ * Greedy per-class NMS with the Sph2Pob IoU as overlap: keep[i] = 1 iff sorted box i survives.
+ * Replaces sph_nms_op (sphdet/bbox/nms/sph_nms.py:62-74: python while-loop, one full IoU pipeline + host sync per
+ * kept box) for every class at once.  Input boxes must be sorted by (class ascending, score descending);
+ * cls_sorted may be NULL (class-agnostic).  A box j is suppressed by an earlier kept box i of the same class when
+ * IoU(box_i as bboxes1, box_j as bboxes2) > iou_threshold (`iou <= thr` keeps, :72).  variant: EFFICIENT (what
+ * SphNMS('sph2pob_efficient') uses, sph_nms.py:9-10) or STANDARD.  k <= sph2pob_nms_max_boxes();
+ * workspace: device buffer of sph2pob_nms_workspace_bytes(k) bytes (the k x ceil(k/64) suppression bit-matrix).
+ */
+int sph2pob_nms_max_boxes(void);
+int64_t sph2pob_nms_workspace_bytes(int64_t k);
+int sph2pob_nms_f32(const float* boxes_sorted, const int64_t* cls_sorted, int64_t k, int box_dim, int variant,
+                    float iou_threshold, void* workspace, unsigned char* keep, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,4 +4,7 @@ from . import _lib  # noqa: F401
 from .iou import (SphOverlaps2D, sph2pob_efficient_iou, sph2pob_legacy_iou, sph2pob_standard_iou,  # noqa: F401
                   sph_overlaps)
 
+from .losses import Sph2PobIoULoss, SphIoULoss  # noqa: F401,E402
+from .bbox.nms import SphNMS, multiclass_nms  # noqa: F401,E402
+
 __version__ = '0.1.0'

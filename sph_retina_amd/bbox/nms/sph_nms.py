@@ -1,0 +1,89 @@
+"""Spherical NMS — mirrors sphdet/bbox/nms/sph_nms.py:7-74 (SphNMS, sph_batched_nms, sph_nms_op).
+
+The reference loops in Python: per class, per kept box, one full Sph2Pob IoU pipeline (1 x K) and a host sync.
+Here all classes go through TWO kernels (`sph2pob_nms_f32`): the suppression bit-matrix with the Sph2Pob IoU
+evaluated once per same-class pair, and a single-wave greedy sweep.  Host work is sorting / gathering only.
+
+Kept behaviour: accepted calculator names, `iou <= thr` keeps, per-class suppression regardless of
+`class_agnostic` (the reference pops the flag but never uses it, :34,44), final ordering by descending score,
+`max_num`, dets = cat(boxes, scores).  Differences: ties are broken deterministically (stable sorts; the reference's
+`torch.argsort(descending=True)` is unstable); `nms_cfg=None` raises instead of `sys.exit()` (:24-28).
+"""
+import ctypes
+
+import torch
+
+from ... import _lib
+from ... import _torch_glue as G
+
+_CALCULATORS = {'sph2pob_efficient': 'efficient', 'sph2pob_efficient_iou': 'efficient',
+                'sph2pob_standard': 'standard', 'sph2pob_standard_iou': 'standard'}
+
+
+def _nms_sorted(boxes_sorted, cls_sorted, iou_threshold, variant):
+    """keep flags (uint8, K) for boxes sorted by (class, -score)."""
+    k, dim = boxes_sorted.shape
+    lib = _lib.lib()
+    if k > lib.sph2pob_nms_max_boxes():
+        raise ValueError(f'sph nms supports at most {lib.sph2pob_nms_max_boxes()} boxes per call, got {k}')
+    dev = boxes_sorted.device
+    keep = torch.empty((k,), dtype=torch.uint8, device=dev)
+    if k == 0:
+        return keep
+    ws = torch.empty((lib.sph2pob_nms_workspace_bytes(k) // 8,), dtype=torch.int64, device=dev)
+    G.call('sph2pob_nms_f32', dev, G.ptr(boxes_sorted), G.ptr(cls_sorted), ctypes.c_int64(k), dim, G.VARIANTS[variant],
+           ctypes.c_float(iou_threshold), G.ptr(ws), G.ptr(keep), G.stream_of(boxes_sorted))
+    return keep
+
+
+def sph_nms_op(boxes, scores, iou_threshold, iou_calculator='sph2pob_efficient'):
+    """Single-class greedy NMS -> indices of kept boxes in descending-score order (reference :62-74)."""
+    variant = _CALCULATORS[iou_calculator] if isinstance(iou_calculator, str) else iou_calculator
+    assert boxes.size(1) in [4, 5]
+    G.require_hip(boxes, scores)
+    order = torch.argsort(scores, descending=True, stable=True)
+    flags = _nms_sorted(G.as_f32(boxes[order]), None, float(iou_threshold), variant)
+    return order[flags.bool()]
+
+
+def sph_batched_nms(boxes, scores, idxs, nms_cfg, iou_calculator='efficient', class_agnostic=False):
+    """Reference sph_batched_nms (:22-60) -> (dets (K', d+1), keep (K',) int64 indices into the input)."""
+    if nms_cfg is None:
+        raise ValueError('nms_cfg is None (the reference prints a message and calls sys.exit() here)')
+    nms_cfg_ = nms_cfg.copy()
+    nms_cfg_.pop('class_agnostic', class_agnostic)  # accepted and ignored, as in the reference
+    nms_cfg_.pop('type', 'nms')
+    nms_cfg_.pop('split_thr', 10000)
+    iou_threshold = nms_cfg_.pop('iou_threshold', 0.5)
+    max_num = min(nms_cfg_.pop('max_num', boxes.shape[0]), boxes.shape[0])
+    G.require_hip(boxes, scores, idxs)
+    assert boxes.size(1) in [4, 5]
+    # sort by (class ascending, score descending): two stable sorts
+    by_score = torch.argsort(scores, descending=True, stable=True)
+    order = by_score[torch.argsort(idxs[by_score], stable=True)]
+    flags = _nms_sorted(G.as_f32(boxes[order]), idxs[order].to(torch.int64).contiguous(), float(iou_threshold),
+                        iou_calculator)
+    total_mask = torch.zeros(scores.shape, dtype=torch.bool, device=scores.device)
+    total_mask[order] = flags.bool()
+    keep = total_mask.nonzero(as_tuple=False).view(-1)           # ascending original index (reference :49)
+    inds = torch.argsort(scores[keep], descending=True, stable=True)
+    keep = keep[inds][:max_num]
+    dets = torch.cat([boxes[keep], scores[keep][:, None]], -1)
+    return dets, keep
+
+
+class SphNMS:
+    """SphNMS(iou_calculator='sph2pob_efficient')(boxes, scores, idxs, nms_cfg, class_agnostic=False)."""
+
+    def __init__(self, iou_calculator='sph2pob_efficient'):
+        if iou_calculator in _CALCULATORS:
+            self.variant = _CALCULATORS[iou_calculator]
+        elif iou_calculator in ('unbiased_iou', 'naive_iou'):
+            raise NotImplementedError(
+                f"SphNMS('{iou_calculator}') is not on the Sph2Pob hot path served by sph_retina_amd (SURVEY §8f-4)")
+        else:
+            raise TypeError('Not supported iou_calculator.')  # the reference's `raise NotImplemented(...)`
+        self.iou_calculator = iou_calculator
+
+    def __call__(self, boxes, scores, idxs, nms_cfg, class_agnostic=False):
+        return sph_batched_nms(boxes, scores, idxs, nms_cfg, self.variant, class_agnostic)

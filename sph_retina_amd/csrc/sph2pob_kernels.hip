@@ -159,6 +159,81 @@ __global__ __launch_bounds__(kBlock) void sum_pass2(const float* __restrict__ ws
     if (threadIdx.x == 0) out[0] = r * scale;
 }
 
+// ---- NMS (replaces the python greedy loop of sph_nms_op, sphdet/bbox/nms/sph_nms.py:62-74) ----
+// Boxes arrive sorted by (class, descending score).  Kernel 1: one wave per (row i, 64-column word w) evaluates
+// IoU(box_i [role bboxes1], box_j [role bboxes2]) > thr for the 64 columns j = 64w + lane (j > i, same class)
+// and emits the 64-bit suppression word with one ballot — no LDS, no atomics.  Kernel 2: a single wave sweeps
+// the rows in order; the greedy dependency inside a 64-row block is resolved on the 64x64 diagonal block held
+// one row per lane (readlane, scalar bit ops), then the kept rows of the block are OR-ed into the running
+// "removed" bit-vector (LDS) with lanes striding over the words, so global loads are never on the serial chain.
+template <int VARIANT, int DIM>
+__global__ __launch_bounds__(kBlock) void nms_mask_kernel(const float* __restrict__ boxes,
+                                                         const int64_t* __restrict__ cls, int64_t k, int words,
+                                                         float thr, unsigned long long* __restrict__ mask) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = blockIdx.x * (kBlock / 64) + wave;
+    const int64_t i = blockIdx.y;
+    if (w >= words) return;
+    const int64_t j0 = (int64_t)w * 64, j1 = (j0 + 63 < k - 1) ? j0 + 63 : k - 1;
+    bool skip = j1 <= i;
+    int64_t ci = 0;
+    if (cls && !skip) {
+        ci = cls[i];
+        skip = cls[j1] < ci || cls[j0 > i ? j0 : i] > ci;  // sorted by class: no column of this word shares row i's class
+    }
+    if (skip) {  // wave-uniform
+        if (lane == 0) mask[i * words + w] = 0ull;
+        return;
+    }
+    const int64_t j = j0 + lane;
+    bool hit = false;
+    if (j < k && j > i && (!cls || cls[j] == ci)) {
+        float x[5], y[5];
+        load_box<DIM>(boxes, i, x);
+        load_box<DIM>(boxes, j, y);
+        hit = pair_iou<VARIANT, DIM>(x, y, MODE_IOU, EDGE_ARC, ANGLE_EQUATOR) > thr;
+    }
+    unsigned long long bits = __ballot(hit);
+    if (lane == 0) mask[i * words + w] = bits;
+}
+
+constexpr int kNmsMaxWords = 512;  // K <= 32768 boxes per call
+
+__global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long* __restrict__ mask, int64_t k,
+                                                       int words, unsigned char* __restrict__ keep) {
+    __shared__ unsigned long long removed[kNmsMaxWords];
+    const int lane = threadIdx.x;
+    for (int w = lane; w < words; w += 64) removed[w] = 0ull;
+    __syncthreads();
+    for (int b = 0; b < words; b++) {
+        const int64_t row = (int64_t)b * 64 + lane;
+        unsigned long long diag = row < k ? mask[row * words + b] : 0ull;
+        unsigned long long rem = removed[b];
+        const int nrow = (k - (int64_t)b * 64 < 64) ? (int)(k - (int64_t)b * 64) : 64;
+        unsigned long long keepbits = 0ull;
+        for (int r = 0; r < nrow; r++) {  // wave-uniform serial chain: registers only
+            unsigned lo = __builtin_amdgcn_readlane((unsigned)(diag & 0xffffffffull), r);
+            unsigned hi = __builtin_amdgcn_readlane((unsigned)(diag >> 32), r);
+            if (!((rem >> r) & 1ull)) {
+                keepbits |= 1ull << r;
+                rem |= ((unsigned long long)hi << 32) | lo;
+            }
+        }
+        if (row < k) keep[row] = (unsigned char)((keepbits >> lane) & 1ull);
+        // OR the kept rows of this block into the later words of the removed vector
+        for (int w = b + 1 + lane; w < words; w += 64) {
+            unsigned long long acc = 0ull, kb = keepbits;
+            while (kb) {
+                int r = __builtin_ctzll(kb);
+                kb &= kb - 1;
+                acc |= mask[((int64_t)b * 64 + r) * words + w];
+            }
+            removed[w] |= acc;
+        }
+        __syncthreads();
+    }
+}
+
 int check_common(int box_dim, int variant, int edge, int angle) {
     if (box_dim != 4 && box_dim != 5) return SPH2POB_ERR_DIM;
     if (variant < 0 || variant > 2 || edge < 0 || edge > 2 || angle < 0 || angle > 1) return SPH2POB_ERR_OPTION;
@@ -311,6 +386,38 @@ int sph2pob_sum_f32(const float* x, int64_t n, float scale, float* out, float* w
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(sum_pass1, dim3(nb), dim3(kBlock), 0, s, x, n, workspace);
     hipLaunchKernelGGL(sum_pass2, dim3(1), dim3(kBlock), 0, s, workspace, nb, scale, out);
+    return launch_status();
+}
+
+int sph2pob_nms_max_boxes(void) { return kNmsMaxWords * 64; }
+
+int64_t sph2pob_nms_workspace_bytes(int64_t k) {
+    int64_t words = (k + 63) / 64;
+    return k * words * 8;
+}
+
+int sph2pob_nms_f32(const float* boxes_sorted, const int64_t* cls_sorted, int64_t k, int box_dim, int variant,
+                    float iou_threshold, void* workspace, unsigned char* keep, void* stream) {
+    if (box_dim != 4 && box_dim != 5) return SPH2POB_ERR_DIM;
+    if (variant != SPH2POB_VARIANT_STANDARD && variant != SPH2POB_VARIANT_EFFICIENT) return SPH2POB_ERR_OPTION;
+    if (k < 0 || k > (int64_t)kNmsMaxWords * 64) return SPH2POB_ERR_SIZE;
+    if (k == 0) return SPH2POB_OK;
+    if (!boxes_sorted || !workspace || !keep) return SPH2POB_ERR_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    const int words = (int)((k + 63) / 64);
+    unsigned long long* mask = (unsigned long long*)workspace;
+    const int wpb = kBlock / 64;
+    dim3 grid((unsigned)((words + wpb - 1) / wpb), (unsigned)k);
+    if (variant == SPH2POB_VARIANT_EFFICIENT) {
+        if (box_dim == 4) hipLaunchKernelGGL((nms_mask_kernel<1, 4>), grid, dim3(kBlock), 0, s, boxes_sorted, cls_sorted, k, words, iou_threshold, mask);
+        else hipLaunchKernelGGL((nms_mask_kernel<1, 5>), grid, dim3(kBlock), 0, s, boxes_sorted, cls_sorted, k, words, iou_threshold, mask);
+    } else {
+        if (box_dim == 4) hipLaunchKernelGGL((nms_mask_kernel<0, 4>), grid, dim3(kBlock), 0, s, boxes_sorted, cls_sorted, k, words, iou_threshold, mask);
+        else hipLaunchKernelGGL((nms_mask_kernel<0, 5>), grid, dim3(kBlock), 0, s, boxes_sorted, cls_sorted, k, words, iou_threshold, mask);
+    }
+    int rc = launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(64), 0, s, mask, k, words, keep);
     return launch_status();
 }
 

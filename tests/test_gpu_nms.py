@@ -1,0 +1,98 @@
+"""GPU: SphNMS (suppression bit-matrix + single-wave sweep) vs the reference keep lists (fixtures) and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def N():
+    import sph_retina_amd.bbox.nms as nms
+    assert torch.cuda.is_available()
+    return nms
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_reference_scenario_and_random_scenes(N):
+    g = load_golden('nms')
+    nms = N.SphNMS(iou_calculator='sph2pob_efficient')
+    dets, keep = nms(cu(g['boxes']), cu(g['scores']), cu(g['idxs']), dict(type='nms', iou_threshold=0.5))
+    assert keep.tolist() == [0, 5, 7, 3, 8, 9]  # reference tests/test_nms.py scenario, SURVEY App. C.4
+    np.testing.assert_allclose(dets.cpu().numpy(), g['dets'], atol=1e-6)
+    assert keep.dtype == torch.int64 and dets.shape == (6, 5)
+    dets, keep = nms(cu(g['rboxes']), cu(g['rscores']), cu(g['ridxs']), dict(type='nms', iou_threshold=0.5, max_num=100))
+    assert keep.tolist() == g['rkeep'].tolist()
+    np.testing.assert_allclose(dets.cpu().numpy(), g['rdets'], atol=1e-6)
+    dets, keep = nms(cu(g['r5boxes']), cu(g['r5scores']), cu(g['r5idxs']), dict(type='nms', iou_threshold=0.4))
+    assert keep.tolist() == g['r5keep'].tolist()
+    assert dets.shape[1] == 6
+
+
+def test_config4_size_5000_boxes_37_classes_vs_oracle(N, oracle):
+    """BASELINE config 4 NMS half: K = 5 x nms_pre(1000) boxes, 37 classes, thr 0.5, max_per_img 100."""
+    rng = np.random.default_rng(4)
+    k = 5000
+    centres = oracle.generate_boxes(300, 8, alpha=(5, 60), beta=(5, 60))
+    boxes = centres[rng.integers(0, 300, k)] + rng.standard_normal((k, 4)).astype(np.float32) * 2.0
+    boxes[:, 0] %= 360
+    boxes[:, 1] = boxes[:, 1].clip(1, 179)
+    boxes[:, 2:] = boxes[:, 2:].clip(2, 120)
+    scores = rng.random(k).astype(np.float32)
+    idxs = rng.integers(0, 37, k)
+    dets, keep = N.SphNMS()(cu(boxes), cu(scores), cu(idxs), dict(type='nms', iou_threshold=0.5, max_num=100))
+    odets, okeep = oracle.batched_nms(boxes, scores, idxs, 0.5, max_num=100)
+    assert keep.tolist() == okeep.tolist()
+    np.testing.assert_allclose(dets.cpu().numpy(), odets, atol=1e-6)
+    # full keep set (no max_num): allow the rare threshold flip (an IoU within fp32 noise of 0.5)
+    _, keep_all = N.SphNMS()(cu(boxes), cu(scores), cu(idxs), dict(type='nms', iou_threshold=0.5))
+    _, okeep_all = oracle.batched_nms(boxes, scores, idxs, 0.5)
+    a, b = set(keep_all.tolist()), set(okeep_all.tolist())
+    assert len(a ^ b) <= 2, (len(a), len(b), len(a ^ b))
+    s = scores[keep_all.cpu().numpy()]
+    assert (np.diff(s) <= 0).all()  # descending score order
+
+
+def test_single_class_op_and_edge_cases(N, oracle):
+    rng = np.random.default_rng(1)
+    b = oracle.generate_boxes(700, 3, alpha=(10, 50), beta=(10, 50))
+    b[:, :2] = np.array([100, 90], np.float32) + rng.standard_normal((700, 2)).astype(np.float32) * 15
+    s = rng.random(700).astype(np.float32)
+    keep = N.sph_nms_op(cu(b), cu(s), 0.3)
+    okeep = oracle.nms_op(b, s, 0.3)
+    assert len(set(keep.tolist()) ^ set(okeep.tolist())) <= 1
+    # idempotence: NMS of the survivors keeps all of them
+    kb, ks = cu(b)[keep], cu(s)[keep]
+    again = N.sph_nms_op(kb, ks, 0.3)
+    assert again.numel() == keep.numel()
+    # empty, single box, all identical boxes, RBFoV
+    dets, keep = N.SphNMS()(cu(b[:0]), cu(s[:0]), cu(np.zeros(0, np.int64)), dict(iou_threshold=0.5))
+    assert dets.shape == (0, 5) and keep.numel() == 0
+    dets, keep = N.SphNMS()(cu(b[:1]), cu(s[:1]), cu(np.zeros(1, np.int64)), dict(iou_threshold=0.5))
+    assert keep.tolist() == [0]
+    same = np.repeat(b[:1], 130, axis=0)
+    dets, keep = N.SphNMS()(cu(same), cu(s[:130]), cu(np.zeros(130, np.int64)), dict(iou_threshold=0.5))
+    assert keep.tolist() == [int(np.argmax(s[:130]))]
+    with pytest.raises(ValueError):
+        N.SphNMS()(cu(b), cu(s), cu(np.zeros(700, np.int64)), None)
+    with pytest.raises(NotImplementedError):
+        N.SphNMS('unbiased_iou')
+
+
+def test_multiclass_nms_wrapper(N, oracle):
+    rng = np.random.default_rng(2)
+    n, c = 300, 4
+    boxes = oracle.generate_boxes(n, 5, alpha=(10, 50), beta=(10, 50))
+    boxes[:, :2] = np.array([200, 80], np.float32) + rng.standard_normal((n, 2)).astype(np.float32) * 20
+    ms = rng.random((n, c + 1)).astype(np.float32)
+    dets, labels, inds = N.multiclass_nms(cu(boxes), cu(ms), 0.3, dict(type='nms', iou_threshold=0.5), max_num=50,
+                                          return_inds=True, nms_op=N.SphNMS(), box_version=4)
+    assert dets.shape[1] == 5 and dets.shape[0] <= 50 and labels.shape[0] == dets.shape[0]
+    flat_scores = ms[:, :-1].reshape(-1)
+    np.testing.assert_allclose(dets[:, 4].cpu().numpy(), flat_scores[inds.cpu().numpy()], atol=0)
+    assert (np.diff(dets[:, 4].cpu().numpy()) <= 0).all() and float(dets[:, 4].min()) > 0.3
