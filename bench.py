@@ -83,6 +83,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--pairs', type=int, default=PAIRS_PER_GPU, help='pairs per GPU per step')
     ap.add_argument('--variant', default=VARIANT, choices=['standard', 'efficient', 'legacy'])
+    ap.add_argument('--arithmetic', default='fast', choices=['fast', 'reference'],
+                    help="'fast' = default closed-form core; 'reference' = the reference's fp32 operation order")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -108,6 +110,7 @@ def main():
     shard = gathered[rank * n:(rank + 1) * n]  # the kernel writes straight into its slot of the gathered vector
     lib = _lib.lib()
     stream = torch.cuda.current_stream(dev)
+    G.set_arithmetic(args.arithmetic)
     variant_c = G.VARIANTS[args.variant]
 
     def step():
@@ -164,7 +167,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': f'{n:,} uniform random BFoV pairs per GPU, sph2pob_{args.variant}_iou aligned '
                                    f'(BASELINE configs[1]{"; x%d shards + RCCL all-gather = configs[4]" % world if world > 1 else ""})',
-                       'pairs_per_gpu': n, 'variant': args.variant, 'parallelism': f'shard{world}'},
+                       'pairs_per_gpu': n, 'variant': args.variant, 'arithmetic': args.arithmetic, 'parallelism': f'shard{world}'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(),
                          'kernel': 'iou_aligned_kernel', 'kernel_ms': kernel_ms,

@@ -1,6 +1,7 @@
 """sph_retina_amd — MI355X-native Sph2Pob spherical-IoU engine (drop-in for the reference's sphdet.iou /
 sphdet.losses / sphdet.bbox.nms operator surface; kernels in csrc/, C ABI in include/sph2pob_hip.h)."""
 from . import _lib  # noqa: F401
+from ._torch_glue import get_arithmetic, set_arithmetic  # noqa: F401
 from .iou import (SphOverlaps2D, sph2pob_efficient_iou, sph2pob_legacy_iou, sph2pob_standard_iou,  # noqa: F401
                   sph_overlaps)
 

@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 LIB_DIR = os.path.join(_HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libsph2pob_hip.so')
 SOURCES = ['sph2pob_kernels.hip']
-HEADERS = ['sph2pob_device.hpp', 'sph2pob_loss.hpp', os.path.join('..', '..', 'include', 'sph2pob_hip.h')]
+HEADERS = ['sph2pob_device.hpp', 'sph2pob_loss.hpp', 'sph2pob_fast.hpp', os.path.join('..', '..', 'include', 'sph2pob_hip.h')]
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off']
 
 _c_f32p = ctypes.c_void_p

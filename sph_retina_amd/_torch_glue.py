@@ -6,7 +6,30 @@ import torch
 
 from . import _lib
 
-VARIANTS = {'standard': 0, 'efficient': 1, 'legacy': 2}
+import os
+
+_VARIANT_CODES = {'standard': 0, 'efficient': 1, 'legacy': 2}
+FLAG_REFERENCE_ORDER = 0x100
+_ARITHMETIC = os.environ.get('SPH2POB_ARITHMETIC', 'fast')
+
+
+def set_arithmetic(mode):
+    """'fast' (default): closed-form geometry core; 'reference': the reference's fp32 operation order."""
+    global _ARITHMETIC
+    assert mode in ('fast', 'reference')
+    _ARITHMETIC = mode
+
+
+def get_arithmetic():
+    return _ARITHMETIC
+
+
+class _Variants(dict):
+    def __getitem__(self, k):
+        return _VARIANT_CODES[k] | (FLAG_REFERENCE_ORDER if _ARITHMETIC == 'reference' else 0)
+
+
+VARIANTS = _Variants(_VARIANT_CODES)
 MODES = {'iou': 0, 'iof': 1}
 EDGES = {'arc': 0, 'chord': 1, 'tangent': 2}
 ANGLES = {'equator': 0, 'project': 1}

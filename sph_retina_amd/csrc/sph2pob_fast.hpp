@@ -1,0 +1,213 @@
+// Fast geometry core for the default Sph2Pob IoU path (variants standard / efficient, rbb_angle='equator').
+//
+// sph2pob_standard and sph2pob_efficient produce the SAME pair of planar boxes up to a rigid translation
+// (g at (-A/2, pi/2) | (0, 0), p at (+A/2, pi/2) | (A, 0), same widths, same angles), so one
+// core serves both.  Instead of re-tracing the reference's ~100 tensor ops (cross products, six F.normalize =
+// 18 IEEE divides, 3-6 acos, 4 planar sin/cos), the core evaluates the same quantities in closed form:
+//
+//     N  =  c_p . d_g ,  D  = -c_p . e_g        (d = meridian tangent, e = c x d = east; bearing of p seen from g)
+//     N' = -c_g . d_p ,  D' =  c_g . e_p
+//     sin A = |(N, D)| ,  cos A = c_g . c_p      A = great-circle distance of the centres
+//     (cos a_g, sin a_g) = (D , N ) / sin A      — the reference's  sign * acos(clamp(d^ . z^))  (sph2pob_efficient.py:81-97)
+//     (cos a_p, sin a_p) = (D', N') / sin A
+//
+// with the theta difference taken BEFORE the trig (sin/cos of (theta_p - theta_g)/2, haversine style), which is
+// better conditioned than the reference's products of separately rounded sin/cos — the core sits below the
+// reference's own fp32 noise floor.  The planar angles are never formed: the clipping stage needs
+// only (cos, sin); gamma (RBFoV) and the jitter's constant angle bumps are applied as rotations of (cos, sin).
+// What IS mirrored exactly: both jitters (decisions on the same quantities with the same thresholds), the rounding
+// of deg->rad, and the acos(clamp(., +-(1 - 1e-7))) floors of the reference (A >= 4.88e-4 [efficient] /
+// 9.77e-4 [standard], |sin a| >= 4.88e-4).  Pairs whose bounding circles cannot touch return 0 early — exact,
+// because disjoint rectangles give exactly 0 in the reference.
+#pragma once
+#include "sph2pob_device.hpp"
+
+namespace sph2pob {
+
+SPH_DEV float fast_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+SPH_DEV float fast_rsq(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsqf(x);
+#else
+    return 1.0f / sqrtf(x);
+#endif
+}
+
+// sin and cos of x (|x| <= ~8 rad) to ~1 ulp: Cody-Waite reduction by pi/2 + Cephes minimax polynomials.
+SPH_DEV void sincos_r(float x, float& s, float& c) {
+    float k = rintf(x * 0.63661977236758134f);
+    float r = fmaf(-k, 1.5703125f, x);
+    r = fmaf(-k, 4.837512969970703125e-4f, r);
+    r = fmaf(-k, 7.549789954891882e-8f, r);
+    float z = r * r;
+    float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    float sp = fmaf(r * z, ps, r);
+    float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    float cp = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+    int q = (int)k & 3;
+    float a = (q & 1) ? cp : sp;
+    float b = (q & 1) ? sp : cp;
+    s = (q & 2) ? -a : a;
+    c = ((q + 1) & 2) ? -b : b;
+}
+
+// atan(t), 0 <= t <= 1 (|err| <= 1.3e-7): odd polynomial of degree 17, near-minimax fit.
+SPH_DEV float atan_unit(float t) {
+    float u = t * t;
+    float p = 0.0028340641874819994f;
+    p = fmaf(p, u, -0.016005029901862144f);
+    p = fmaf(p, u, 0.042587608098983765f);
+    p = fmaf(p, u, -0.07495445758104324f);
+    p = fmaf(p, u, 0.10636754333972931f);
+    p = fmaf(p, u, -0.14202570915222168f);
+    p = fmaf(p, u, 0.19992484152317047f);
+    p = fmaf(p, u, -0.3333306610584259f);
+    return fmaf(p * u, t, t);
+}
+SPH_DEV float atan2_r(float y, float x) {
+    float ax = fabsf(x), ay = fabsf(y);
+    float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float t = mx > 0.0f ? mn * fast_rcp(mx) : 0.0f;
+    t = fminf(t, 1.0f);
+    float p = atan_unit(t);
+    p = ay > ax ? 1.57079632679489662f - p : p;
+    p = x < 0.0f ? 3.14159265358979324f - p : p;
+    return y < 0.0f ? -p : p;
+}
+
+constexpr float kMinAng = 4.8828125e-4f;     // acos(float(1 - 1e-7))
+constexpr float kCosMinAng = 0.99999988f;    // cos(kMinAng) in fp32 = the clamp bound itself
+
+// rotate (c, s) by +ang where (ca, sa) = (cos ang, sin ang)
+SPH_DEV void rot(float& c, float& s, float ca, float sa) {
+    float c2 = c * ca - s * sa, s2 = s * ca + c * sa;
+    c = c2;
+    s = s2;
+}
+
+// the reference's  sign * |acos(clamp(cos a))|  expressed on (cos a, sin a): floor |a| and |pi - a| at kMinAng;
+// sin a == 0 takes the negative sign (criterion `< 0` false -> -1, sph2pob_efficient.py:211-226)
+SPH_DEV void angle_floor(float& c, float& s) {
+    if (fabsf(s) < kMinAng) {
+        s = s > 0.0f ? kMinAng : -kMinAng;
+        c = c < 0.0f ? -kCosMinAng : kCosMinAng;
+    }
+}
+
+// VARIANT: 0 standard, 1 efficient.  Returns clamp(IoU, 0, 1) of one pair.
+template <int VARIANT, int DIM>
+SPH_DEV float pair_iou_fast(const float (&in1)[5], const float (&in2)[5], int mode, int edge) {
+    float b1[5], b2[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) { b1[k] = in1[k]; b2[k] = in2[k]; }
+    jitter_spherical<DIM>(b1, b2);
+
+    // degrees -> radians with the reference's rounding (torch.deg2rad: x * fl32(pi/180))
+    float thg = b1[0] * kDeg2Rad, phg = b1[1] * kDeg2Rad, thp = b2[0] * kDeg2Rad, php = b2[1] * kDeg2Rad;
+    float wg = edge_length(b1[2] * kDeg2Rad, edge), hg = edge_length(b1[3] * kDeg2Rad, edge);
+    float wp = edge_length(b2[2] * kDeg2Rad, edge), hp = edge_length(b2[3] * kDeg2Rad, edge);
+
+    float sg, cg, sp, cp, sh, ch;
+    sincos_r(phg, sg, cg);
+    sincos_r(php, sp, cp);
+    sincos_r(0.5f * (thp - thg), sh, ch);
+    float sD = 2.0f * sh * ch;   // sin(theta_p - theta_g)
+    float h2 = 2.0f * sh * sh;   // 1 - cos(theta_p - theta_g)
+    float q = sp * cg - cp * sg; // sin(phi_p - phi_g)
+    float N = q - sp * cg * h2, D = -sp * sD;
+    float Np = q + sg * cp * h2, Dp = -sg * sD;
+    float C = (cg * cp + sg * sp) - sg * sp * h2;
+    float S2 = N * N + D * D;
+
+    // ---- exact early-out: circumscribed circles of the two planar rectangles cannot touch ----
+    float R = 0.5f * (sqrtf(wg * wg + hg * hg) + sqrtf(wp * wp + hp * hp)) + 1.5e-3f;  // + jitter & noise margin
+    float R2 = R * R;
+    float cosR_lb = fmaf(fmaf(fmaf(-1.0f / 720.0f, R2, 1.0f / 24.0f), R2, -0.5f), R2, 1.0f);  // <= cos R
+    if (R < 3.0f && C < cosR_lb) return 0.0f;
+
+    // rare configurations handled by the reference-order path: (near-)coincident centres where the reference
+    // switches its rotation-matrix construction (sph2pob_standard.py:286-297), or gamma so large that the
+    // rotated jitter's +-2*pi angle clamp (sph_iou_api.py:239-240) could act
+    bool rare = S2 < 1e-13f;
+    if (DIM == 5) rare |= fabsf(b1[4]) > 179.8f || fabsf(b2[4]) > 179.8f;
+    if (rare) return pair_iou<VARIANT, DIM>(in1, in2, mode, edge, ANGLE_EQUATOR);
+
+    float iS = fast_rsq(S2);
+    float S = S2 * iS;
+    float A = atan2_r(S, C);
+    A = fmaxf(A, VARIANT == VARIANT_STANDARD ? 2.0f * kMinAng : kMinAng);
+    float ca = D * iS, sa = N * iS, cb = Dp * iS, sb = Np * iS;
+    float ga = 0.0f, gb = 0.0f;
+    if (DIM == 5) {
+        ga = b1[4] * kDeg2Rad;
+        gb = b2[4] * kDeg2Rad;
+        float sga, cga, sgb, cgb;
+        sincos_r(ga, sga, cga);
+        sincos_r(gb, sgb, cgb);
+        if (VARIANT == VARIANT_EFFICIENT) { angle_floor(ca, sa); angle_floor(cb, sb); }  // floor, then a -= gamma
+        rot(ca, sa, cga, -sga);
+        rot(cb, sb, cgb, -sgb);
+        if (VARIANT == VARIANT_STANDARD) { angle_floor(ca, sa); angle_floor(cb, sb); }   // d rotated first
+    } else {
+        angle_floor(ca, sa);
+        angle_floor(cb, sb);
+    }
+
+    // ---- rotated jitter (sph_iou_api.py:222-242) on (x, w, h, a); decisions need real angles only when the
+    // two angles are within ~1.8e-3 of each other modulo 2*pi ----
+    const float e = (float)kEpsS, ea = (float)kEpsA;
+    float cdel = ca * cb + sa * sb, sdel = sa * cb - ca * sb;  // cos / sin of (a_g - a_p)
+    bool sim = (A < e) | (fabsf(wg - wp) < e) | (fabsf(hg - hp) < e);
+    bool close = false;
+    if (cdel > 0.5f && fabsf(sdel) < 2.0e-3f) {
+        float a1, a2;
+        if (DIM == 5 && VARIANT == VARIANT_EFFICIENT) {  // a = floor(atan2(N, D)) - gamma, not wrapped
+            float c1 = D * iS, s1 = N * iS, c2 = Dp * iS, s2 = Np * iS;
+            angle_floor(c1, s1);
+            angle_floor(c2, s2);
+            a1 = atan2_r(s1, c1) - ga;
+            a2 = atan2_r(s2, c2) - gb;
+        } else {
+            a1 = atan2_r(sa, ca);
+            a2 = atan2_r(sb, cb);
+        }
+        sim |= fabsf(a1 - a2) < e;
+        if (sim) { a1 += e; a2 += (float)(5 * kEpsS); }
+        close = fabsf(a1 - a2) < ea;
+    }
+    float dx = A, dy = 0.0f;
+    if (sim) {
+        dx += e; dy += e;  // (x, y) += (e, e) vs (2e, 2e)
+        wg += (float)(2 * kEpsS); hg += (float)(2 * kEpsS); wp += e; hp += e;
+        rot(ca, sa, (float)0.99999999237921, (float)1.2345678e-4);   // cos/sin(e)
+        rot(cb, sb, (float)0.99999980948025, (float)6.172838961e-4); // cos/sin(5e)
+    }
+    if (close) {
+        rot(ca, sa, (float)0.99999923792122, (float)1.2345674864e-3);  // cos/sin(ea)
+        rot(cb, sb, (float)0.99999695168547, (float)2.4691330913e-3);  // cos/sin(2ea)
+    }
+    wg = fmaxf(wg, (float)(2 * kEpsA / 10)); hg = fmaxf(hg, (float)(2 * kEpsA / 10));
+    wp = fmaxf(wp, (float)(kEpsA / 10));     hp = fmaxf(hp, (float)(kEpsA / 10));
+
+    // ---- planar intersection (boundary integral, see sph2pob_device.hpp) ----
+    float c = ca * cb + sa * sb, s = sa * cb - ca * sb;
+    float ic = fast_rcp(c), is = fast_rcp(s);
+    float hwa = 0.5f * wg, hha = 0.5f * hg, hwb = 0.5f * wp, hhb = 0.5f * hp;
+    float pax = -(dx * cb + dy * sb), pay = -(dy * cb - dx * sb);
+    float pbx = dx * ca + dy * sa, pby = dy * ca - dx * sa;
+    float t2 = edges_inside(pax, pay, c, s, ic, is, hwa, hha, hwb, hhb, wg, hg, true) +
+               edges_inside(pbx, pby, c, -s, ic, -is, hwb, hhb, hwa, hha, wp, hp, false);
+    float inter = 0.5f * fmaxf(t2, 0.0f);
+    float a1 = wg * hg, a2 = wp * hp;
+    float base = mode == MODE_IOU ? (a1 + a2 - inter) : a1;
+    float iou = inter / base;
+    return fminf(fmaxf(iou, 0.0f), 1.0f);
+}
+
+}  // namespace sph2pob

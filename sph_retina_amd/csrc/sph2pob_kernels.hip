@@ -5,6 +5,7 @@
 #include "../../include/sph2pob_hip.h"
 #include "sph2pob_device.hpp"
 #include "sph2pob_loss.hpp"
+#include "sph2pob_fast.hpp"
 
 namespace {
 
@@ -24,7 +25,15 @@ __device__ __forceinline__ void load_box(const float* __restrict__ p, int64_t i,
     }
 }
 
-template <int VARIANT, int DIM>
+// FAST: the closed-form core of sph2pob_fast.hpp (standard / efficient with rbb_angle='equator'); otherwise the
+// reference-order path of sph2pob_device.hpp (legacy, rbb_angle='project').
+template <int VARIANT, int DIM, bool FAST>
+__device__ __forceinline__ float pair_iou_sel(const float (&x)[5], const float (&y)[5], int mode, int edge, int angle) {
+    if constexpr (FAST) return pair_iou_fast<VARIANT, DIM>(x, y, mode, edge);
+    else return pair_iou<VARIANT, DIM>(x, y, mode, edge, angle);
+}
+
+template <int VARIANT, int DIM, bool FAST>
 __global__ __launch_bounds__(kBlock) void iou_aligned_kernel(const float* __restrict__ b1,
                                                             const float* __restrict__ b2,
                                                             float* __restrict__ out, int64_t n, int mode, int edge,
@@ -34,11 +43,11 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_kernel(const float* __rest
     float x[5], y[5];
     load_box<DIM>(b1, i, x);
     load_box<DIM>(b2, i, y);
-    out[i] = pair_iou<VARIANT, DIM>(x, y, mode, edge, angle);
+    out[i] = pair_iou_sel<VARIANT, DIM, FAST>(x, y, mode, edge, angle);
 }
 
 // out[i*n + j]: consecutive lanes walk j (coalesced stores, b2 loads coalesced, b1 row is a broadcast).
-template <int VARIANT, int DIM>
+template <int VARIANT, int DIM, bool FAST>
 __global__ __launch_bounds__(kBlock) void iou_pairwise_kernel(const float* __restrict__ b1, int64_t m,
                                                              const float* __restrict__ b2, int64_t n,
                                                              float* __restrict__ out, int mode, int edge,
@@ -49,7 +58,7 @@ __global__ __launch_bounds__(kBlock) void iou_pairwise_kernel(const float* __res
     float x[5], y[5];
     load_box<DIM>(b1, i, x);
     load_box<DIM>(b2, j, y);
-    out[i * n + j] = pair_iou<VARIANT, DIM>(x, y, mode, edge, angle);
+    out[i * n + j] = pair_iou_sel<VARIANT, DIM, FAST>(x, y, mode, edge, angle);
 }
 
 template <int VARIANT, int DIM>
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(kBlock) void sum_pass2(const float* __restrict__ ws
 // the rows in order; the greedy dependency inside a 64-row block is resolved on the 64x64 diagonal block held
 // one row per lane (readlane, scalar bit ops), then the kept rows of the block are OR-ed into the running
 // "removed" bit-vector (LDS) with lanes striding over the words, so global loads are never on the serial chain.
-template <int VARIANT, int DIM>
+template <int VARIANT, int DIM, bool FAST>
 __global__ __launch_bounds__(kBlock) void nms_mask_kernel(const float* __restrict__ boxes,
                                                          const int64_t* __restrict__ cls, int64_t k, int words,
                                                          float thr, unsigned long long* __restrict__ mask) {
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(kBlock) void nms_mask_kernel(const float* __restric
         float x[5], y[5];
         load_box<DIM>(boxes, i, x);
         load_box<DIM>(boxes, j, y);
-        hit = pair_iou<VARIANT, DIM>(x, y, MODE_IOU, EDGE_ARC, ANGLE_EQUATOR) > thr;
+        hit = pair_iou_sel<VARIANT, DIM, FAST>(x, y, MODE_IOU, EDGE_ARC, ANGLE_EQUATOR) > thr;
     }
     unsigned long long bits = __ballot(hit);
     if (lane == 0) mask[i * words + w] = bits;
@@ -234,7 +243,9 @@ __global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long*
     }
 }
 
-int check_common(int box_dim, int variant, int edge, int angle) {
+int check_common(int box_dim, int variant_flags, int edge, int angle) {
+    const int variant = variant_flags & 0xff;
+    if (variant_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER)) return SPH2POB_ERR_OPTION;
     if (box_dim != 4 && box_dim != 5) return SPH2POB_ERR_DIM;
     if (variant < 0 || variant > 2 || edge < 0 || edge > 2 || angle < 0 || angle > 1) return SPH2POB_ERR_OPTION;
     if (variant == SPH2POB_VARIANT_LEGACY && box_dim == 5) return SPH2POB_ERR_DIM;
@@ -248,30 +259,39 @@ int launch_status() {
 
 // dispatch a (VARIANT, DIM) pair to a functor
 template <typename F>
-int dispatch(int variant, int box_dim, F&& f) {
+int dispatch(int variant_flags, int box_dim, F&& f) {
+    const int variant = variant_flags & 0xff;
+    f.fast = !(variant_flags & SPH2POB_FLAG_REFERENCE_ORDER);
     if (variant == SPH2POB_VARIANT_STANDARD) return box_dim == 4 ? f.template run<0, 4>() : f.template run<0, 5>();
     if (variant == SPH2POB_VARIANT_EFFICIENT) return box_dim == 4 ? f.template run<1, 4>() : f.template run<1, 5>();
     return f.template run<2, 4>();
 }
 
 struct AlignedLaunch {
-    const float *b1, *b2; float* out; int64_t n; int mode, edge, angle; hipStream_t s;
+    const float *b1, *b2; float* out; int64_t n; int mode, edge, angle; hipStream_t s; bool fast = true;
     template <int V, int D> int run() {
         dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-        hipLaunchKernelGGL((iou_aligned_kernel<V, D>), grid, dim3(kBlock), 0, s, b1, b2, out, n, mode, edge, angle);
+        if (fast && V != 2 && angle == SPH2POB_ANGLE_EQUATOR)
+            hipLaunchKernelGGL((iou_aligned_kernel<V == 2 ? 0 : V, D, true>), grid, dim3(kBlock), 0, s, b1, b2, out, n, mode, edge, angle);
+        else
+            hipLaunchKernelGGL((iou_aligned_kernel<V, D, false>), grid, dim3(kBlock), 0, s, b1, b2, out, n, mode, edge, angle);
         return launch_status();
     }
 };
 struct PairwiseLaunch {
-    const float* b1; int64_t m; const float* b2; int64_t n; float* out; int mode, edge, angle; hipStream_t s;
+    const float* b1; int64_t m; const float* b2; int64_t n; float* out; int mode, edge, angle; hipStream_t s; bool fast = true;
     template <int V, int D> int run() {
         // grid.y is limited to 65535 rows per launch: walk the rows in slabs
         const int64_t kMaxRows = 65535;
         for (int64_t r0 = 0; r0 < m; r0 += kMaxRows) {
             int64_t rows = m - r0 < kMaxRows ? m - r0 : kMaxRows;
             dim3 grid((unsigned)((n + kBlock - 1) / kBlock), (unsigned)rows);
-            hipLaunchKernelGGL((iou_pairwise_kernel<V, D>), grid, dim3(kBlock), 0, s, b1 + r0 * D, rows, b2, n,
-                               out + r0 * n, mode, edge, angle);
+            if (fast && V != 2 && angle == SPH2POB_ANGLE_EQUATOR)
+                hipLaunchKernelGGL((iou_pairwise_kernel<V == 2 ? 0 : V, D, true>), grid, dim3(kBlock), 0, s, b1 + r0 * D, rows,
+                                   b2, n, out + r0 * n, mode, edge, angle);
+            else
+                hipLaunchKernelGGL((iou_pairwise_kernel<V, D, false>), grid, dim3(kBlock), 0, s, b1 + r0 * D, rows, b2, n,
+                                   out + r0 * n, mode, edge, angle);
             int rc = launch_status();
             if (rc) return rc;
         }
@@ -279,7 +299,7 @@ struct PairwiseLaunch {
     }
 };
 struct TransformLaunch {
-    const float *b1, *b2; float *o1, *o2; int64_t n; int edge, angle, jitter; hipStream_t s;
+    const float *b1, *b2; float *o1, *o2; int64_t n; int edge, angle, jitter; hipStream_t s; bool fast = true;
     template <int V, int D> int run() {
         dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
         hipLaunchKernelGGL((transform_kernel<V, D>), grid, dim3(kBlock), 0, s, b1, b2, o1, o2, n, edge, angle, jitter);
@@ -396,8 +416,11 @@ int64_t sph2pob_nms_workspace_bytes(int64_t k) {
     return k * words * 8;
 }
 
-int sph2pob_nms_f32(const float* boxes_sorted, const int64_t* cls_sorted, int64_t k, int box_dim, int variant,
+int sph2pob_nms_f32(const float* boxes_sorted, const int64_t* cls_sorted, int64_t k, int box_dim, int variant_flags,
                     float iou_threshold, void* workspace, unsigned char* keep, void* stream) {
+    const int variant = variant_flags & 0xff;
+    const bool fast = !(variant_flags & SPH2POB_FLAG_REFERENCE_ORDER);
+    if (variant_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER)) return SPH2POB_ERR_OPTION;
     if (box_dim != 4 && box_dim != 5) return SPH2POB_ERR_DIM;
     if (variant != SPH2POB_VARIANT_STANDARD && variant != SPH2POB_VARIANT_EFFICIENT) return SPH2POB_ERR_OPTION;
     if (k < 0 || k > (int64_t)kNmsMaxWords * 64) return SPH2POB_ERR_SIZE;
@@ -408,13 +431,16 @@ int sph2pob_nms_f32(const float* boxes_sorted, const int64_t* cls_sorted, int64_
     unsigned long long* mask = (unsigned long long*)workspace;
     const int wpb = kBlock / 64;
     dim3 grid((unsigned)((words + wpb - 1) / wpb), (unsigned)k);
+#define SPH_NMS_LAUNCH(V, D, F) \
+    hipLaunchKernelGGL((nms_mask_kernel<V, D, F>), grid, dim3(kBlock), 0, s, boxes_sorted, cls_sorted, k, words, iou_threshold, mask)
     if (variant == SPH2POB_VARIANT_EFFICIENT) {
-        if (box_dim == 4) hipLaunchKernelGGL((nms_mask_kernel<1, 4>), grid, dim3(kBlock), 0, s, boxes_sorted, cls_sorted, k, words, iou_threshold, mask);
-        else hipLaunchKernelGGL((nms_mask_kernel<1, 5>), grid, dim3(kBlock), 0, s, boxes_sorted, cls_sorted, k, words, iou_threshold, mask);
+        if (box_dim == 4) { if (fast) SPH_NMS_LAUNCH(1, 4, true); else SPH_NMS_LAUNCH(1, 4, false); }
+        else { if (fast) SPH_NMS_LAUNCH(1, 5, true); else SPH_NMS_LAUNCH(1, 5, false); }
     } else {
-        if (box_dim == 4) hipLaunchKernelGGL((nms_mask_kernel<0, 4>), grid, dim3(kBlock), 0, s, boxes_sorted, cls_sorted, k, words, iou_threshold, mask);
-        else hipLaunchKernelGGL((nms_mask_kernel<0, 5>), grid, dim3(kBlock), 0, s, boxes_sorted, cls_sorted, k, words, iou_threshold, mask);
+        if (box_dim == 4) { if (fast) SPH_NMS_LAUNCH(0, 4, true); else SPH_NMS_LAUNCH(0, 4, false); }
+        else { if (fast) SPH_NMS_LAUNCH(0, 5, true); else SPH_NMS_LAUNCH(0, 5, false); }
     }
+#undef SPH_NMS_LAUNCH
     int rc = launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(64), 0, s, mask, k, words, keep);

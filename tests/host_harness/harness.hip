@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include "../../sph_retina_amd/csrc/sph2pob_device.hpp"
 #include "../../sph_retina_amd/csrc/sph2pob_loss.hpp"
+#include "../../sph_retina_amd/csrc/sph2pob_fast.hpp"
 
 using namespace sph2pob;
 
@@ -28,7 +29,21 @@ static void iou_loop(const float* b1, const float* b2, int64_t n, int mode, int 
     }
 }
 
+template <int V, int DIM>
+static void iou_fast_loop(const float* b1, const float* b2, int64_t n, int mode, int edge, float* out) {
+    for (int64_t i = 0; i < n; i++) {
+        float x[5] = {0, 0, 0, 0, 0}, y[5] = {0, 0, 0, 0, 0};
+        for (int k = 0; k < DIM; k++) { x[k] = b1[i * DIM + k]; y[k] = b2[i * DIM + k]; }
+        out[i] = pair_iou_fast<V, DIM>(x, y, mode, edge);
+    }
+}
+
 extern "C" {
+int harness_iou_fast(const float* b1, const float* b2, int64_t n, int dim, int variant, int mode, int edge, float* out) {
+    if (variant == 0) { if (dim == 4) iou_fast_loop<0, 4>(b1, b2, n, mode, edge, out); else iou_fast_loop<0, 5>(b1, b2, n, mode, edge, out); }
+    else { if (dim == 4) iou_fast_loop<1, 4>(b1, b2, n, mode, edge, out); else iou_fast_loop<1, 5>(b1, b2, n, mode, edge, out); }
+    return 0;
+}
 int harness_loss(const float* pred, const float* target, int64_t n, int dim, int mode, float eps, float* loss,
                  float* iou, float* gp, float* gt) {
     if (dim == 4) loss_loop<4>(pred, target, n, mode, eps, loss, iou, gp, gt);
