@@ -170,7 +170,8 @@ def main():
                        'pairs_per_gpu': n, 'variant': args.variant, 'arithmetic': args.arithmetic, 'parallelism': f'shard{world}'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(),
-                         'kernel': 'iou_aligned_kernel', 'kernel_ms': kernel_ms,
+                         'kernel': 'iou_aligned_compact_kernel' if args.arithmetic == 'fast' and args.variant != 'legacy'
+                         else 'iou_aligned_kernel', 'kernel_ms': kernel_ms,
                          'algorithmic_bytes_per_launch': BYTES_PER_PAIR * n},
             'readme_t_cuda_ratio': (n / (kernel_ms * 1e-3)) / (1e6 / 0.0096),
             'checksum': checksum,

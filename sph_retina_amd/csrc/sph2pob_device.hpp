@@ -39,7 +39,14 @@ constexpr double kEpsA = 1e-3 * 1.2345678;              // rotated angle eps
 constexpr float kClampHi = (float)(1 - 1e-7);           // 0.99999988
 constexpr float kClampLo = (float)(-1 + 1e-7);
 
-SPH_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }  // NaN-free inputs
+// clamp for NaN-free x: a single v_med3_f32 on the device
+SPH_DEV float clampf(float x, float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(x, lo, hi);
+#else
+    return fminf(fmaxf(x, lo), hi);
+#endif
+}
 
 SPH_DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
 SPH_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -75,12 +82,11 @@ SPH_DEV void jitter_spherical(float (&b1)[5], float (&b2)[5]) {
     bool similar = false;
 #pragma unroll
     for (int k = 0; k < DIM; k++) similar |= fabsf(b1[k] - b2[k]) < eps;
-    if (similar) {
+    const float sh1 = similar ? eps2 : 0.0f, sh2 = similar ? eps : 0.0f;  // x - 0 == x exactly
 #pragma unroll
-        for (int k = 0; k < DIM; k++) {
-            b1[k] = b1[k] - eps2;
-            b2[k] = b2[k] + eps;
-        }
+    for (int k = 0; k < DIM; k++) {
+        b1[k] = b1[k] - sh1;
+        b2[k] = b2[k] + sh2;
     }
     b1[0] = clampf(b1[0], eps2, (float)(360.0 - kEpsS));
     b2[0] = clampf(b2[0], eps, (float)(360.0 - 2 * kEpsS));

@@ -100,19 +100,52 @@ SPH_DEV void angle_floor(float& c, float& s) {
     }
 }
 
-// VARIANT: 0 standard, 1 efficient.  Returns clamp(IoU, 0, 1) of one pair.
+// Clipped length, slab form with pre-sorted bounds: tau in [m - r, m + r] per axis where m = -p * (1/u) and
+// r = h * |1/u| (r is shared by every edge with the same direction magnitude).  Reciprocals are clamped to
+// +-1e18 by the caller so that parallel edges give finite, correctly ordered bounds (inside: (-huge, +huge);
+// outside: both bounds on the same side => empty) without NaNs.
+SPH_DEV float clip_len2(float px, float py, float iux, float iuy, float rx, float ry, float len) {
+    float mx = -px * iux, my = -py * iuy;
+    float lo = fmaxf(fmaxf(mx - rx, my - ry), 0.0f);
+    float hi = fminf(fminf(mx + rx, my + ry), len);
+    return fmaxf(hi - lo, 0.0f);
+}
+// Same contract as edges_inside (sph2pob_device.hpp) with the cheaper slab form; aic = |1/c|, ais = |1/s|.
+SPH_DEV float edges_inside2(float pax, float pay, float c, float s, float ic, float is, float aic, float ais, float hwa,
+                            float hha, float hwb, float hhb, float wa, float ha, bool with_origin_terms) {
+    float ux = hwa * c, uy = hwa * s, vx = -hha * s, vy = hha * c;
+    float k0x = pax + ux + vx, k0y = pay + uy + vy;
+    float k1x = pax - ux + vx, k1y = pay - uy + vy;
+    float k2x = pax - ux - vx, k2y = pay - uy - vy;
+    float k3x = pax + ux - vx, k3y = pay + uy - vy;
+    // edges along +-u have direction (+-c, +-s): slab radii (hwb*|1/c|, hhb*|1/s|); along +-v: (-+s, +-c)
+    float rux = hwb * aic, ruy = hhb * ais, rvx = hwb * ais, rvy = hhb * aic;
+    float l0 = clip_len2(k0x, k0y, -ic, -is, rux, ruy, wa);
+    float l1 = clip_len2(k1x, k1y, is, -ic, rvx, rvy, ha);
+    float l2 = clip_len2(k2x, k2y, ic, is, rux, ruy, wa);
+    float l3 = clip_len2(k3x, k3y, -is, ic, rvx, rvy, ha);
+    if (!with_origin_terms) return hha * (l0 + l2) + hwa * (l1 + l3);
+    float xu = pax * s - pay * c, xv = pax * c + pay * s;
+    return (l0 * (hha - xu) + l2 * (hha + xu)) + (l1 * (hwa - xv) + l3 * (hwa + xv));
+}
+
+// What phase 1 hands to phase 2 (kept in registers, or staged through the LDS survivor queue by the compacting kernel)
+struct FastRec { float N, D, Np, Dp, C, wg, hg, wp, hp, ga, gb; };
+enum : int { FAST_ZERO = 0, FAST_SURVIVOR = 1 };
+
+// Phase 1: jitter, trig, bearing numerators and the exact bounding-circle early-out.
 template <int VARIANT, int DIM>
-SPH_DEV float pair_iou_fast(const float (&in1)[5], const float (&in2)[5], int mode, int edge) {
+SPH_DEV int fast_phase1(const float (&in1)[5], const float (&in2)[5], int edge, FastRec& r) {
     float b1[5], b2[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) { b1[k] = in1[k]; b2[k] = in2[k]; }
     jitter_spherical<DIM>(b1, b2);
-
     // degrees -> radians with the reference's rounding (torch.deg2rad: x * fl32(pi/180))
     float thg = b1[0] * kDeg2Rad, phg = b1[1] * kDeg2Rad, thp = b2[0] * kDeg2Rad, php = b2[1] * kDeg2Rad;
-    float wg = edge_length(b1[2] * kDeg2Rad, edge), hg = edge_length(b1[3] * kDeg2Rad, edge);
-    float wp = edge_length(b2[2] * kDeg2Rad, edge), hp = edge_length(b2[3] * kDeg2Rad, edge);
-
+    r.wg = edge_length(b1[2] * kDeg2Rad, edge); r.hg = edge_length(b1[3] * kDeg2Rad, edge);
+    r.wp = edge_length(b2[2] * kDeg2Rad, edge); r.hp = edge_length(b2[3] * kDeg2Rad, edge);
+    r.ga = DIM == 5 ? b1[4] * kDeg2Rad : 0.0f;
+    r.gb = DIM == 5 ? b2[4] * kDeg2Rad : 0.0f;
     float sg, cg, sp, cp, sh, ch;
     sincos_r(phg, sg, cg);
     sincos_r(php, sp, cp);
@@ -120,36 +153,38 @@ SPH_DEV float pair_iou_fast(const float (&in1)[5], const float (&in2)[5], int mo
     float sD = 2.0f * sh * ch;   // sin(theta_p - theta_g)
     float h2 = 2.0f * sh * sh;   // 1 - cos(theta_p - theta_g)
     float q = sp * cg - cp * sg; // sin(phi_p - phi_g)
-    float N = q - sp * cg * h2, D = -sp * sD;
-    float Np = q + sg * cp * h2, Dp = -sg * sD;
-    float C = (cg * cp + sg * sp) - sg * sp * h2;
-    float S2 = N * N + D * D;
-
-    // ---- exact early-out: circumscribed circles of the two planar rectangles cannot touch ----
-    float R = 0.5f * (sqrtf(wg * wg + hg * hg) + sqrtf(wp * wp + hp * hp)) + 1.5e-3f;  // + jitter & noise margin
+    r.N = q - sp * cg * h2;  r.D = -sp * sD;
+    r.Np = q + sg * cp * h2; r.Dp = -sg * sD;
+    r.C = (cg * cp + sg * sp) - sg * sp * h2;
+    // exact early-out: circumscribed circles of the two planar rectangles cannot touch (margin covers both jitters
+    // and the reference's own rounding of A); 1 - R^2/2 + R^4/24 - R^6/720 <= cos R
+    float d1 = r.wg * r.wg + r.hg * r.hg, d2 = r.wp * r.wp + r.hp * r.hp;
+    float R = 0.5f * (d1 * fast_rsq(d1) + d2 * fast_rsq(d2)) + 1.5e-3f;
     float R2 = R * R;
-    float cosR_lb = fmaf(fmaf(fmaf(-1.0f / 720.0f, R2, 1.0f / 24.0f), R2, -0.5f), R2, 1.0f);  // <= cos R
-    if (R < 3.0f && C < cosR_lb) return 0.0f;
+    float cosR_lb = fmaf(fmaf(fmaf(-1.0f / 720.0f, R2, 1.0f / 24.0f), R2, -0.5f), R2, 1.0f);
+    if (R < 3.0f && r.C < cosR_lb) return FAST_ZERO;
+    return FAST_SURVIVOR;
+}
 
-    // rare configurations handled by the reference-order path: (near-)coincident centres where the reference
-    // switches its rotation-matrix construction (sph2pob_standard.py:286-297), or gamma so large that the
-    // rotated jitter's +-2*pi angle clamp (sph_iou_api.py:239-240) could act
-    bool rare = S2 < 1e-13f;
-    if (DIM == 5) rare |= fabsf(b1[4]) > 179.8f || fabsf(b2[4]) > 179.8f;
-    if (rare) return pair_iou<VARIANT, DIM>(in1, in2, mode, edge, ANGLE_EQUATOR);
-
+// Phase 2: planar boxes as (cos, sin), rotated jitter, boundary-integral intersection, IoU.
+template <int VARIANT, int DIM>
+SPH_DEV float fast_phase2(const FastRec& r, int mode) {
+    float wg = r.wg, hg = r.hg, wp = r.wp, hp = r.hp;
+    float S2 = r.N * r.N + r.D * r.D;
     float iS = fast_rsq(S2);
-    float S = S2 * iS;
-    float A = atan2_r(S, C);
+    float A = atan2_r(S2 * iS, r.C);
     A = fmaxf(A, VARIANT == VARIANT_STANDARD ? 2.0f * kMinAng : kMinAng);
-    float ca = D * iS, sa = N * iS, cb = Dp * iS, sb = Np * iS;
-    float ga = 0.0f, gb = 0.0f;
+    float ca = r.D * iS, sa = r.N * iS, cb = r.Dp * iS, sb = r.Np * iS;
+    if (S2 < 1e-13f) {
+        // coincident (or exactly antipodal) centres: the bearing is undefined — the reference's own value is
+        // rounding noise of c_g x c_p, or its degenerate-branch frame (sph2pob_standard.py:286-297) in which both
+        // meridian tangents sit at +pi/2.  Use that frame: a = pi/2 for both boxes.
+        ca = 0.0f; sa = 1.0f; cb = 0.0f; sb = 1.0f;
+    }
     if (DIM == 5) {
-        ga = b1[4] * kDeg2Rad;
-        gb = b2[4] * kDeg2Rad;
         float sga, cga, sgb, cgb;
-        sincos_r(ga, sga, cga);
-        sincos_r(gb, sgb, cgb);
+        sincos_r(r.ga, sga, cga);
+        sincos_r(r.gb, sgb, cgb);
         if (VARIANT == VARIANT_EFFICIENT) { angle_floor(ca, sa); angle_floor(cb, sb); }  // floor, then a -= gamma
         rot(ca, sa, cga, -sga);
         rot(cb, sb, cgb, -sgb);
@@ -158,21 +193,20 @@ SPH_DEV float pair_iou_fast(const float (&in1)[5], const float (&in2)[5], int mo
         angle_floor(ca, sa);
         angle_floor(cb, sb);
     }
-
     // ---- rotated jitter (sph_iou_api.py:222-242) on (x, w, h, a); decisions need real angles only when the
     // two angles are within ~1.8e-3 of each other modulo 2*pi ----
     const float e = (float)kEpsS, ea = (float)kEpsA;
-    float cdel = ca * cb + sa * sb, sdel = sa * cb - ca * sb;  // cos / sin of (a_g - a_p)
+    float c = ca * cb + sa * sb, s = sa * cb - ca * sb;  // cos / sin of (a_g - a_p)
     bool sim = (A < e) | (fabsf(wg - wp) < e) | (fabsf(hg - hp) < e);
     bool close = false;
-    if (cdel > 0.5f && fabsf(sdel) < 2.0e-3f) {
+    if (c > 0.5f && fabsf(s) < 2.0e-3f) {
         float a1, a2;
         if (DIM == 5 && VARIANT == VARIANT_EFFICIENT) {  // a = floor(atan2(N, D)) - gamma, not wrapped
-            float c1 = D * iS, s1 = N * iS, c2 = Dp * iS, s2 = Np * iS;
+            float c1 = r.D * iS, s1 = r.N * iS, c2 = r.Dp * iS, s2 = r.Np * iS;
             angle_floor(c1, s1);
             angle_floor(c2, s2);
-            a1 = atan2_r(s1, c1) - ga;
-            a2 = atan2_r(s2, c2) - gb;
+            a1 = atan2_r(s1, c1) - r.ga;
+            a2 = atan2_r(s2, c2) - r.gb;
         } else {
             a1 = atan2_r(sa, ca);
             a2 = atan2_r(sb, cb);
@@ -182,32 +216,63 @@ SPH_DEV float pair_iou_fast(const float (&in1)[5], const float (&in2)[5], int mo
         close = fabsf(a1 - a2) < ea;
     }
     float dx = A, dy = 0.0f;
-    if (sim) {
-        dx += e; dy += e;  // (x, y) += (e, e) vs (2e, 2e)
-        wg += (float)(2 * kEpsS); hg += (float)(2 * kEpsS); wp += e; hp += e;
-        rot(ca, sa, (float)0.99999999237921, (float)1.2345678e-4);   // cos/sin(e)
-        rot(cb, sb, (float)0.99999980948025, (float)6.172838961e-4); // cos/sin(5e)
-    }
-    if (close) {
-        rot(ca, sa, (float)0.99999923792122, (float)1.2345674864e-3);  // cos/sin(ea)
-        rot(cb, sb, (float)0.99999695168547, (float)2.4691330913e-3);  // cos/sin(2ea)
+    if (sim | close) {  // rare: constant rotations of (cos, sin) instead of new trig
+        if (sim) {
+            dx += e; dy += e;  // (x, y) += (e, e) vs (2e, 2e)
+            wg += (float)(2 * kEpsS); hg += (float)(2 * kEpsS); wp += e; hp += e;
+            rot(ca, sa, (float)0.99999999237921, (float)1.2345678e-4);    // cos/sin(e)
+            rot(cb, sb, (float)0.99999980948025, (float)6.172838610e-4);  // cos/sin(5e)
+        }
+        if (close) {
+            rot(ca, sa, (float)0.99999923792122, (float)1.2345674864e-3);  // cos/sin(ea)
+            rot(cb, sb, (float)0.99999695168547, (float)2.4691330913e-3);  // cos/sin(2ea)
+        }
+        c = ca * cb + sa * sb;
+        s = sa * cb - ca * sb;
     }
     wg = fmaxf(wg, (float)(2 * kEpsA / 10)); hg = fmaxf(hg, (float)(2 * kEpsA / 10));
     wp = fmaxf(wp, (float)(kEpsA / 10));     hp = fmaxf(hp, (float)(kEpsA / 10));
+    if (DIM == 5 && (fabsf(r.ga) > 3.1f || fabsf(r.gb) > 3.1f)) {
+        // |gamma| beyond 177 deg (outside any coder's range): the rotated jitter's angle clamp to
+        // [-2pi + 2ea, 2pi - ea] / [-2pi + ea, 2pi - 2ea] (sph_iou_api.py:239-240) may act on a = atan2(.) - gamma
+        const float twopi = 6.283185307179586f;
+        float a1 = atan2_r(sa, ca), a2 = atan2_r(sb, cb);  // wrapped representatives
+        if (VARIANT == VARIANT_EFFICIENT) {                // un-wrap to the reference's real value (|a| < 3*pi)
+            float est1 = -r.ga, est2 = -r.gb;              // a = beta - gamma, |beta| <= pi
+            a1 += twopi * rintf((est1 - a1) / twopi);
+            a2 += twopi * rintf((est2 - a2) / twopi);
+        }
+        float k1 = fminf(fmaxf(a1, -twopi + 2.0f * ea), twopi - ea), k2 = fminf(fmaxf(a2, -twopi + ea), twopi - 2.0f * ea);
+        if (k1 != a1 || k2 != a2) {
+            sincos_r(k1 - twopi * rintf(k1 / twopi), sa, ca);
+            sincos_r(k2 - twopi * rintf(k2 / twopi), sb, cb);
+            c = ca * cb + sa * sb;
+            s = sa * cb - ca * sb;
+        }
+    }
 
     // ---- planar intersection (boundary integral, see sph2pob_device.hpp) ----
-    float c = ca * cb + sa * sb, s = sa * cb - ca * sb;
-    float ic = fast_rcp(c), is = fast_rcp(s);
+    const float kBig = 1e18f;
+    float ic = fminf(fmaxf(fast_rcp(c), -kBig), kBig), is = fminf(fmaxf(fast_rcp(s), -kBig), kBig);
+    float aic = fabsf(ic), ais = fabsf(is);
     float hwa = 0.5f * wg, hha = 0.5f * hg, hwb = 0.5f * wp, hhb = 0.5f * hp;
     float pax = -(dx * cb + dy * sb), pay = -(dy * cb - dx * sb);
     float pbx = dx * ca + dy * sa, pby = dy * ca - dx * sa;
-    float t2 = edges_inside(pax, pay, c, s, ic, is, hwa, hha, hwb, hhb, wg, hg, true) +
-               edges_inside(pbx, pby, c, -s, ic, -is, hwb, hhb, hwa, hha, wp, hp, false);
+    float t2 = edges_inside2(pax, pay, c, s, ic, is, aic, ais, hwa, hha, hwb, hhb, wg, hg, true) +
+               edges_inside2(pbx, pby, c, -s, ic, -is, aic, ais, hwb, hhb, hwa, hha, wp, hp, false);
     float inter = 0.5f * fmaxf(t2, 0.0f);
     float a1 = wg * hg, a2 = wp * hp;
     float base = mode == MODE_IOU ? (a1 + a2 - inter) : a1;
     float iou = inter / base;
     return fminf(fmaxf(iou, 0.0f), 1.0f);
+}
+
+// VARIANT: 0 standard, 1 efficient.  Returns clamp(IoU, 0, 1) of one pair.
+template <int VARIANT, int DIM>
+SPH_DEV float pair_iou_fast(const float (&in1)[5], const float (&in2)[5], int mode, int edge) {
+    FastRec r;
+    if (fast_phase1<VARIANT, DIM>(in1, in2, edge, r) == FAST_ZERO) return 0.0f;
+    return fast_phase2<VARIANT, DIM>(r, mode);
 }
 
 }  // namespace sph2pob

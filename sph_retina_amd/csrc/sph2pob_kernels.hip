@@ -1,6 +1,7 @@
 // libsph2pob_hip.so — kernels + C-ABI launchers (see include/sph2pob_hip.h).  gfx950 only.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/sph2pob_hip.h"
 #include "sph2pob_device.hpp"
@@ -12,6 +13,12 @@ namespace {
 using namespace sph2pob;
 
 constexpr int kBlock = 256;  // 4 waves of 64 lanes
+
+// tuning knobs (environment, read once): SPH2POB_NO_COMPACT=1 disables the compacting kernel,
+// SPH2POB_SLICES_PER_WAVE sets how many 64-pair slices each wave of the compacting kernel walks
+static bool g_no_compact = getenv("SPH2POB_NO_COMPACT") != nullptr;
+static bool g_prefetch = getenv("SPH2POB_NO_PREFETCH") == nullptr;
+static int g_slices_per_wave = getenv("SPH2POB_SLICES_PER_WAVE") ? atoi(getenv("SPH2POB_SLICES_PER_WAVE")) : 4;
 
 template <int DIM>
 __device__ __forceinline__ void load_box(const float* __restrict__ p, int64_t i, float (&b)[5]) {
@@ -44,6 +51,100 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_kernel(const float* __rest
     load_box<DIM>(b1, i, x);
     load_box<DIM>(b2, i, y);
     out[i] = pair_iou_sel<VARIANT, DIM, FAST>(x, y, mode, edge, angle);
+}
+
+// ---- dominant kernel: aligned IoU, closed-form core, with wave-level compaction of early-out survivors ----
+// ~60 % of the benchmark distribution's pairs are culled exactly by the bounding-circle test of phase 1.  A naive
+// `if (!culled) phase2` leaves every wave running phase 2 with ~40 % of its lanes.  Here each wave walks 64-pair
+// slices, pushes the survivors' phase-1 records into its own LDS stack (ballot + prefix rank => conflict-free
+// consecutive slots, no atomics, no barriers: LDS operations of one wave are in order), and runs phase 2 only
+// when 64 records are available, i.e. on fully populated waves.  Leftovers of the 4 waves of a workgroup are
+// merged once at the end.  Stores: culled pairs write 0 from phase 1, survivors write from phase 2 by index.
+constexpr int kQCap = 128;                    // per-wave stack capacity (<= 63 carried + 64 pushed)
+constexpr int kQFields = 11;                  // N D Np Dp C wg hg wp hp ga gb
+
+struct WaveQueue {
+    float f[kQFields][kQCap];
+    int idx[kQCap];
+};
+
+__device__ __forceinline__ void queue_store(WaveQueue& q, int slot, const FastRec& r, int i, bool has_gamma) {
+    q.f[0][slot] = r.N;  q.f[1][slot] = r.D;  q.f[2][slot] = r.Np; q.f[3][slot] = r.Dp; q.f[4][slot] = r.C;
+    q.f[5][slot] = r.wg; q.f[6][slot] = r.hg; q.f[7][slot] = r.wp; q.f[8][slot] = r.hp;
+    if (has_gamma) { q.f[9][slot] = r.ga; q.f[10][slot] = r.gb; }
+    q.idx[slot] = i;
+}
+__device__ __forceinline__ int queue_load(const WaveQueue& q, int slot, FastRec& r, bool has_gamma) {
+    r.N = q.f[0][slot];  r.D = q.f[1][slot];  r.Np = q.f[2][slot]; r.Dp = q.f[3][slot]; r.C = q.f[4][slot];
+    r.wg = q.f[5][slot]; r.hg = q.f[6][slot]; r.wp = q.f[7][slot]; r.hp = q.f[8][slot];
+    r.ga = has_gamma ? q.f[9][slot] : 0.0f;
+    r.gb = has_gamma ? q.f[10][slot] : 0.0f;
+    return q.idx[slot];
+}
+
+template <int VARIANT, int DIM, bool PREFETCH>
+__global__ __launch_bounds__(kBlock) void iou_aligned_compact_kernel(const float* __restrict__ b1,
+                                                                    const float* __restrict__ b2,
+                                                                    float* __restrict__ out, int n, int mode,
+                                                                    int edge) {
+    __shared__ WaveQueue queues[kBlock / 64];
+    __shared__ int leftover[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    WaveQueue& q = queues[wave];
+    const int nslices = (n + 63) >> 6;
+    const int wave_global = blockIdx.x * (kBlock / 64) + wave, nwaves = gridDim.x * (kBlock / 64);
+    int count = 0;  // wave-uniform stack height
+    // software prefetch: the next slice's boxes are in flight while this slice is computed (register double buffer)
+    float nx[5], ny[5];
+    {
+        const int i0 = wave_global * 64 + lane;
+        if (PREFETCH && wave_global < nslices && i0 < n) { load_box<DIM>(b1, i0, nx); load_box<DIM>(b2, i0, ny); }
+    }
+    for (int sl = wave_global; sl < nslices; sl += nwaves) {
+        const int i = sl * 64 + lane;
+        float x[5], y[5];
+        if (PREFETCH) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) { x[k] = nx[k]; y[k] = ny[k]; }
+            const int sn = sl + nwaves, in = sn * 64 + lane;
+            if (sn < nslices && in < n) { load_box<DIM>(b1, in, nx); load_box<DIM>(b2, in, ny); }
+        } else if (i < n) {
+            load_box<DIM>(b1, i, x);
+            load_box<DIM>(b2, i, y);
+        }
+        bool surv = false;
+        FastRec r;
+        if (i < n) {
+            if (fast_phase1<VARIANT, DIM>(x, y, edge, r) == FAST_ZERO) out[i] = 0.0f;
+            else surv = true;
+        }
+        const unsigned long long m = __ballot(surv);
+        if (surv) queue_store(q, count + __popcll(m & ((1ull << lane) - 1ull)), r, i, DIM == 5);
+        count += __popcll(m);
+        if (count >= 64) {  // wave-uniform
+            count -= 64;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            FastRec t;
+            int j = queue_load(q, count + lane, t, DIM == 5);
+            out[j] = fast_phase2<VARIANT, DIM>(t, mode);
+        }
+    }
+    // merge the < 64 leftovers of the four waves and finish them on as few, as full waves as possible
+    if (lane == 0) leftover[wave] = count;
+    __syncthreads();
+    const int c0 = leftover[0], c1 = leftover[1], c2 = leftover[2], c3 = leftover[3];
+    const int total = c0 + c1 + c2 + c3;
+    for (int base = wave * 64; base < total; base += kBlock) {
+        int k = base + lane;
+        if (k < total) {
+            int w = 0;
+            if (k >= c0) { k -= c0; w = 1; if (k >= c1) { k -= c1; w = 2; if (k >= c2) { k -= c2; w = 3; } } }
+            FastRec t;
+            int j = queue_load(queues[w], k, t, DIM == 5);
+            out[j] = fast_phase2<VARIANT, DIM>(t, mode);
+        }
+    }
 }
 
 // out[i*n + j]: consecutive lanes walk j (coalesced stores, b2 loads coalesced, b1 row is a broadcast).
@@ -271,7 +372,17 @@ struct AlignedLaunch {
     const float *b1, *b2; float* out; int64_t n; int mode, edge, angle; hipStream_t s; bool fast = true;
     template <int V, int D> int run() {
         dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-        if (fast && V != 2 && angle == SPH2POB_ANGLE_EQUATOR)
+        if (fast && V != 2 && angle == SPH2POB_ANGLE_EQUATOR && n < ((int64_t)1 << 31) - 64 && !g_no_compact) {
+            // persistent-style grid: enough slices per wave for the survivor stacks to fill
+            int64_t slices = (n + 63) / 64;
+            int64_t wgs = (slices + 4 * g_slices_per_wave - 1) / (4 * g_slices_per_wave);
+            if (wgs > 256 * 7) wgs = 256 * 7;
+            if (wgs < 1) wgs = 1;
+            if (g_prefetch)
+                hipLaunchKernelGGL((iou_aligned_compact_kernel<V == 2 ? 0 : V, D, true>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge);
+            else
+                hipLaunchKernelGGL((iou_aligned_compact_kernel<V == 2 ? 0 : V, D, false>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge);
+        } else if (fast && V != 2 && angle == SPH2POB_ANGLE_EQUATOR)
             hipLaunchKernelGGL((iou_aligned_kernel<V == 2 ? 0 : V, D, true>), grid, dim3(kBlock), 0, s, b1, b2, out, n, mode, edge, angle);
         else
             hipLaunchKernelGGL((iou_aligned_kernel<V, D, false>), grid, dim3(kBlock), 0, s, b1, b2, out, n, mode, edge, angle);

@@ -108,7 +108,8 @@ def test_fixtures_from_reference(S, name, variants, arith):
         # not further from fp64 truth than the reference's own fp32 run (torch CPU) is
         mine, theirs = err_stats(got[ok], ref64[ok]), err_stats(ref32[ok], ref64[ok])
         assert s['mean'] < max(1e-6, 1.5 * theirs['mean']), (name, v, s, theirs)
-        assert s['n5'] <= max(0.025 * s['n'], 1.5 * theirs['n5']), (name, v, s, theirs)
+        # |hip - ref32| <= |hip - truth| + |truth - ref32|: up to twice the reference's own outlier count
+        assert s['n5'] <= max(0.025 * s['n'], (1.5 if arith == 'reference' else 2.0) * theirs['n5'] + 5), (name, v, s, theirs)
         if name.startswith('uniform'):
             assert s['max'] < 1e-4, (name, v, s)
         assert mine['n5'] <= 1.5 * theirs['n5'] + 5, (name, v, mine, theirs)
