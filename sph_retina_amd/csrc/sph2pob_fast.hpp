@@ -39,6 +39,23 @@ SPH_DEV float fast_rsq(float x) {
 #endif
 }
 
+// hardware sin/cos (v_sin_f32 / v_cos_f32, argument in revolutions, |abs err| of a few 1e-6): ONLY used by the
+// conservative cull test, never for a value that reaches the output
+SPH_DEV float hw_sin_rev(float rev) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sinf(rev);
+#else
+    return sinf(rev * 6.283185307179586f);
+#endif
+}
+SPH_DEV float hw_cos_rev(float rev) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_cosf(rev);
+#else
+    return cosf(rev * 6.283185307179586f);
+#endif
+}
+
 // sin and cos of x (|x| <= ~8 rad) to ~1 ulp: Cody-Waite reduction by pi/2 + Cephes minimax polynomials.
 SPH_DEV void sincos_r(float x, float& s, float& c) {
     float k = rintf(x * 0.63661977236758134f);
@@ -86,6 +103,7 @@ constexpr float kCosMinAng = 0.99999988f;    // cos(kMinAng) in fp32 = the clamp
 
 // rotate (c, s) by +ang where (ca, sa) = (cos ang, sin ang)
 SPH_DEV void rot(float& c, float& s, float ca, float sa) {
+#pragma clang fp contract(fast)
     float c2 = c * ca - s * sa, s2 = s * ca + c * sa;
     c = c2;
     s = s2;
@@ -100,46 +118,74 @@ SPH_DEV void angle_floor(float& c, float& s) {
     }
 }
 
-// Clipped length, slab form with pre-sorted bounds: tau in [m - r, m + r] per axis where m = -p * (1/u) and
-// r = h * |1/u| (r is shared by every edge with the same direction magnitude).  Reciprocals are clamped to
-// +-1e18 by the caller so that parallel edges give finite, correctly ordered bounds (inside: (-huge, +huge);
-// outside: both bounds on the same side => empty) without NaNs.
-SPH_DEV float clip_len2(float px, float py, float iux, float iuy, float rx, float ry, float len) {
-    float mx = -px * iux, my = -py * iuy;
+// Clipped length of one rectangle edge inside the other rectangle's slabs, pre-sorted-bound form: the edge is
+// P(tau) = k + tau * u^ (tau in [0, len]); per axis tau lies in [m - r, m + r] with m = -k_axis / u^_axis and
+// r = h_axis * |1 / u^_axis|.  Reciprocals are clamped to +-1e18 so that parallel edges give finite, correctly
+// ordered bounds (inside: (-huge, +huge); outside: both bounds on one side => empty) without NaNs.
+SPH_DEV float clip_len3(float mx, float my, float rx, float ry, float len) {
     float lo = fmaxf(fmaxf(mx - rx, my - ry), 0.0f);
     float hi = fminf(fminf(mx + rx, my + ry), len);
     return fmaxf(hi - lo, 0.0f);
 }
-// Same contract as edges_inside (sph2pob_device.hpp) with the cheaper slab form; aic = |1/c|, ais = |1/s|.
-SPH_DEV float edges_inside2(float pax, float pay, float c, float s, float ic, float is, float aic, float ais, float hwa,
-                            float hha, float hwb, float hhb, float wa, float ha, bool with_origin_terms) {
-    float ux = hwa * c, uy = hwa * s, vx = -hha * s, vy = hha * c;
-    float k0x = pax + ux + vx, k0y = pay + uy + vy;
-    float k1x = pax - ux + vx, k1y = pay - uy + vy;
-    float k2x = pax - ux - vx, k2y = pay - uy - vy;
-    float k3x = pax + ux - vx, k3y = pay + uy - vy;
-    // edges along +-u have direction (+-c, +-s): slab radii (hwb*|1/c|, hhb*|1/s|); along +-v: (-+s, +-c)
-    float rux = hwb * aic, ruy = hhb * ais, rvx = hwb * ais, rvy = hhb * aic;
-    float l0 = clip_len2(k0x, k0y, -ic, -is, rux, ruy, wa);
-    float l1 = clip_len2(k1x, k1y, is, -ic, rvx, rvy, ha);
-    float l2 = clip_len2(k2x, k2y, ic, is, rux, ruy, wa);
-    float l3 = clip_len2(k3x, k3y, -is, ic, rvx, rvy, ha);
-    if (!with_origin_terms) return hha * (l0 + l2) + hwa * (l1 + l3);
-    float xu = pax * s - pay * c, xv = pax * c + pay * s;
-    return (l0 * (hha - xu) + l2 * (hha + xu)) + (l1 * (hwa - xv) + l3 * (hwa + xv));
+// Twice the boundary-integral contribution of rectangle X's four edges clipped to rectangle Y (Y's frame):
+// (px, py) = X's centre, half extents hw/hh (full w/h), axes rotated by (c, s); Y = [-hwy, hwy] x [-hhy, hhy];
+// ic = 1/c, is = 1/s (clamped), aic/ais their magnitudes.  Corners are formed first and only then scaled by the
+// reciprocals (m = -k_axis / u^_axis): expanding k * (1/u) into sums of large terms would lose the small
+// differences that decide near-parallel, near-coincident edges (identical boxes after the jitter).
+SPH_DEV float edges_inside3(float px, float py, float c, float s, float ic, float is, float aic, float ais, float hw,
+                            float hh, float hwy, float hhy, float w, float h, bool with_origin_terms) {
+#pragma clang fp contract(fast)
+    float ux = hw * c, uy = hw * s, vx = -hh * s, vy = hh * c;
+    float k0x = (px + ux) + vx, k0y = (py + uy) + vy;
+    float k1x = (px - ux) + vx, k1y = (py - uy) + vy;
+    float k2x = 2.0f * px - k0x, k2y = 2.0f * py - k0y;
+    float k3x = 2.0f * px - k1x, k3y = 2.0f * py - k1y;
+    float rux = hwy * aic, ruy = hhy * ais, rvx = hwy * ais, rvy = hhy * aic;
+    // e0: k0, dir -u^ = (-c, -s); e1: k1, dir -v^ = (s, -c); e2: k2, dir +u^; e3: k3, dir +v^ = (-s, c)
+    float l0 = clip_len3(k0x * ic, k0y * is, rux, ruy, w);
+    float l1 = clip_len3(-k1x * is, k1y * ic, rvx, rvy, h);
+    float l2 = clip_len3(-k2x * ic, -k2y * is, rux, ruy, w);
+    float l3 = clip_len3(k3x * is, -k3y * ic, rvx, rvy, h);
+    if (!with_origin_terms) return hh * (l0 + l2) + hw * (l1 + l3);
+    float xu = px * s - py * c, xv = px * c + py * s;
+    return (l0 * (hh - xu) + l2 * (hh + xu)) + (l1 * (hw - xv) + l3 * (hw + xv));
 }
 
 // What phase 1 hands to phase 2 (kept in registers, or staged through the LDS survivor queue by the compacting kernel)
 struct FastRec { float N, D, Np, Dp, C, wg, hg, wp, hp, ga, gb; };
 enum : int { FAST_ZERO = 0, FAST_SURVIVOR = 1 };
 
-// Phase 1: jitter, trig, bearing numerators and the exact bounding-circle early-out.
-template <int VARIANT, int DIM>
-SPH_DEV int fast_phase1(const float (&in1)[5], const float (&in2)[5], int edge, FastRec& r) {
-    float b1[5], b2[5];
+// Stage 0 (cull): spherical jitter + a conservative bounding-circle test with hardware trig.  Returns true when the
+// pair's IoU is exactly 0 (the two planar rectangles' circumscribed circles cannot touch, whatever the rounding of
+// the accurate path: the bound carries 1.5e-3 rad for both jitters + the reference's own rounding of A, and 1e-4 in
+// cos-space for the hardware trig's error).  j1/j2 receive the jittered boxes (degrees) for the later stages.
+template <int DIM>
+SPH_DEV bool fast_cull(const float (&in1)[5], const float (&in2)[5], int edge, float (&j1)[5], float (&j2)[5]) {
+#pragma clang fp contract(fast)
 #pragma unroll
-    for (int k = 0; k < 5; k++) { b1[k] = in1[k]; b2[k] = in2[k]; }
-    jitter_spherical<DIM>(b1, b2);
+    for (int k = 0; k < 5; k++) { j1[k] = in1[k]; j2[k] = in2[k]; }
+    jitter_spherical<DIM>(j1, j2);
+    float wg = j1[2] * kDeg2Rad, hg = j1[3] * kDeg2Rad, wp = j2[2] * kDeg2Rad, hp = j2[3] * kDeg2Rad;
+    if (edge != EDGE_ARC) {
+        wg = edge_length(wg, edge); hg = edge_length(hg, edge); wp = edge_length(wp, edge); hp = edge_length(hp, edge);
+    }
+    float d1 = wg * wg + hg * hg, d2 = wp * wp + hp * hp;
+    float R = 0.5f * (d1 * fast_rsq(d1) + d2 * fast_rsq(d2)) + 1.5e-3f;
+    if (!(R < 3.0f)) return false;
+    float R2 = R * R;
+    float cosR_lb = fmaf(fmaf(fmaf(-1.0f / 720.0f, R2, 1.0f / 24.0f), R2, -0.5f), R2, 1.0f);  // <= cos R
+    const float kRev = 1.0f / 360.0f;
+    float sg = hw_sin_rev(j1[1] * kRev), cg = hw_cos_rev(j1[1] * kRev);
+    float sp = hw_sin_rev(j2[1] * kRev), cp = hw_cos_rev(j2[1] * kRev);
+    float cD = hw_cos_rev((j2[0] - j1[0]) * kRev);
+    float C = cg * cp + sg * sp * cD;
+    return C < cosR_lb - 1e-4f;
+}
+
+// Stage 1: accurate trig on the jittered boxes, bearing numerators, and the exact early-out on accurate values.
+template <int VARIANT, int DIM>
+SPH_DEV int fast_phase1(const float (&b1)[5], const float (&b2)[5], int edge, FastRec& r) {
+#pragma clang fp contract(fast)
     // degrees -> radians with the reference's rounding (torch.deg2rad: x * fl32(pi/180))
     float thg = b1[0] * kDeg2Rad, phg = b1[1] * kDeg2Rad, thp = b2[0] * kDeg2Rad, php = b2[1] * kDeg2Rad;
     r.wg = edge_length(b1[2] * kDeg2Rad, edge); r.hg = edge_length(b1[3] * kDeg2Rad, edge);
@@ -169,6 +215,7 @@ SPH_DEV int fast_phase1(const float (&in1)[5], const float (&in2)[5], int edge, 
 // Phase 2: planar boxes as (cos, sin), rotated jitter, boundary-integral intersection, IoU.
 template <int VARIANT, int DIM>
 SPH_DEV float fast_phase2(const FastRec& r, int mode) {
+#pragma clang fp contract(fast)
     float wg = r.wg, hg = r.hg, wp = r.wp, hp = r.hp;
     float S2 = r.N * r.N + r.D * r.D;
     float iS = fast_rsq(S2);
@@ -258,8 +305,8 @@ SPH_DEV float fast_phase2(const FastRec& r, int mode) {
     float hwa = 0.5f * wg, hha = 0.5f * hg, hwb = 0.5f * wp, hhb = 0.5f * hp;
     float pax = -(dx * cb + dy * sb), pay = -(dy * cb - dx * sb);
     float pbx = dx * ca + dy * sa, pby = dy * ca - dx * sa;
-    float t2 = edges_inside2(pax, pay, c, s, ic, is, aic, ais, hwa, hha, hwb, hhb, wg, hg, true) +
-               edges_inside2(pbx, pby, c, -s, ic, -is, aic, ais, hwb, hhb, hwa, hha, wp, hp, false);
+    float t2 = edges_inside3(pax, pay, c, s, ic, is, aic, ais, hwa, hha, hwb, hhb, wg, hg, true) +
+               edges_inside3(pbx, pby, c, -s, ic, -is, aic, ais, hwb, hhb, hwa, hha, wp, hp, false);
     float inter = 0.5f * fmaxf(t2, 0.0f);
     float a1 = wg * hg, a2 = wp * hp;
     float base = mode == MODE_IOU ? (a1 + a2 - inter) : a1;
@@ -267,12 +314,20 @@ SPH_DEV float fast_phase2(const FastRec& r, int mode) {
     return fminf(fmaxf(iou, 0.0f), 1.0f);
 }
 
+// Stages 1 + 2 on jittered boxes.
+template <int VARIANT, int DIM>
+SPH_DEV float fast_finish(const float (&j1)[5], const float (&j2)[5], int mode, int edge) {
+    FastRec r;
+    if (fast_phase1<VARIANT, DIM>(j1, j2, edge, r) == FAST_ZERO) return 0.0f;
+    return fast_phase2<VARIANT, DIM>(r, mode);
+}
+
 // VARIANT: 0 standard, 1 efficient.  Returns clamp(IoU, 0, 1) of one pair.
 template <int VARIANT, int DIM>
 SPH_DEV float pair_iou_fast(const float (&in1)[5], const float (&in2)[5], int mode, int edge) {
-    FastRec r;
-    if (fast_phase1<VARIANT, DIM>(in1, in2, edge, r) == FAST_ZERO) return 0.0f;
-    return fast_phase2<VARIANT, DIM>(r, mode);
+    float j1[5], j2[5];
+    if (fast_cull<DIM>(in1, in2, edge, j1, j2)) return 0.0f;
+    return fast_finish<VARIANT, DIM>(j1, j2, mode, edge);
 }
 
 }  // namespace sph2pob

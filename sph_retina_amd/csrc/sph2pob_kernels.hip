@@ -54,31 +54,31 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_kernel(const float* __rest
 }
 
 // ---- dominant kernel: aligned IoU, closed-form core, with wave-level compaction of early-out survivors ----
-// ~60 % of the benchmark distribution's pairs are culled exactly by the bounding-circle test of phase 1.  A naive
+// ~60 % of the benchmark distribution's pairs are culled exactly by the bounding-circle test of stage 0 (hardware
+// sin/cos, conservative margins); only survivors pay for accurate trig and the clip.  A naive
 // `if (!culled) phase2` leaves every wave running phase 2 with ~40 % of its lanes.  Here each wave walks 64-pair
 // slices, pushes the survivors' phase-1 records into its own LDS stack (ballot + prefix rank => conflict-free
 // consecutive slots, no atomics, no barriers: LDS operations of one wave are in order), and runs phase 2 only
 // when 64 records are available, i.e. on fully populated waves.  Leftovers of the 4 waves of a workgroup are
 // merged once at the end.  Stores: culled pairs write 0 from phase 1, survivors write from phase 2 by index.
 constexpr int kQCap = 128;                    // per-wave stack capacity (<= 63 carried + 64 pushed)
-constexpr int kQFields = 11;                  // N D Np Dp C wg hg wp hp ga gb
+constexpr int kQFields = 10;                  // jittered (theta, phi, alpha, beta[, gamma]) of both boxes
 
 struct WaveQueue {
     float f[kQFields][kQCap];
     int idx[kQCap];
 };
 
-__device__ __forceinline__ void queue_store(WaveQueue& q, int slot, const FastRec& r, int i, bool has_gamma) {
-    q.f[0][slot] = r.N;  q.f[1][slot] = r.D;  q.f[2][slot] = r.Np; q.f[3][slot] = r.Dp; q.f[4][slot] = r.C;
-    q.f[5][slot] = r.wg; q.f[6][slot] = r.hg; q.f[7][slot] = r.wp; q.f[8][slot] = r.hp;
-    if (has_gamma) { q.f[9][slot] = r.ga; q.f[10][slot] = r.gb; }
+template <int DIM>
+__device__ __forceinline__ void queue_store(WaveQueue& q, int slot, const float (&j1)[5], const float (&j2)[5], int i) {
+#pragma unroll
+    for (int k = 0; k < DIM; k++) { q.f[k][slot] = j1[k]; q.f[5 + k][slot] = j2[k]; }
     q.idx[slot] = i;
 }
-__device__ __forceinline__ int queue_load(const WaveQueue& q, int slot, FastRec& r, bool has_gamma) {
-    r.N = q.f[0][slot];  r.D = q.f[1][slot];  r.Np = q.f[2][slot]; r.Dp = q.f[3][slot]; r.C = q.f[4][slot];
-    r.wg = q.f[5][slot]; r.hg = q.f[6][slot]; r.wp = q.f[7][slot]; r.hp = q.f[8][slot];
-    r.ga = has_gamma ? q.f[9][slot] : 0.0f;
-    r.gb = has_gamma ? q.f[10][slot] : 0.0f;
+template <int DIM>
+__device__ __forceinline__ int queue_load(const WaveQueue& q, int slot, float (&j1)[5], float (&j2)[5]) {
+#pragma unroll
+    for (int k = 0; k < 5; k++) { j1[k] = k < DIM ? q.f[k][slot] : 0.0f; j2[k] = k < DIM ? q.f[5 + k][slot] : 0.0f; }
     return q.idx[slot];
 }
 
@@ -113,21 +113,21 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_compact_kernel(const float
             load_box<DIM>(b2, i, y);
         }
         bool surv = false;
-        FastRec r;
+        float j1[5], j2[5];
         if (i < n) {
-            if (fast_phase1<VARIANT, DIM>(x, y, edge, r) == FAST_ZERO) out[i] = 0.0f;
+            if (fast_cull<DIM>(x, y, edge, j1, j2)) out[i] = 0.0f;
             else surv = true;
         }
         const unsigned long long m = __ballot(surv);
-        if (surv) queue_store(q, count + __popcll(m & ((1ull << lane) - 1ull)), r, i, DIM == 5);
+        if (surv) queue_store<DIM>(q, count + __popcll(m & ((1ull << lane) - 1ull)), j1, j2, i);
         count += __popcll(m);
         if (count >= 64) {  // wave-uniform
             count -= 64;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            FastRec t;
-            int j = queue_load(q, count + lane, t, DIM == 5);
-            out[j] = fast_phase2<VARIANT, DIM>(t, mode);
+            float u1[5], u2[5];
+            int j = queue_load<DIM>(q, count + lane, u1, u2);
+            out[j] = fast_finish<VARIANT, DIM>(u1, u2, mode, edge);
         }
     }
     // merge the < 64 leftovers of the four waves and finish them on as few, as full waves as possible
@@ -140,9 +140,9 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_compact_kernel(const float
         if (k < total) {
             int w = 0;
             if (k >= c0) { k -= c0; w = 1; if (k >= c1) { k -= c1; w = 2; if (k >= c2) { k -= c2; w = 3; } } }
-            FastRec t;
-            int j = queue_load(queues[w], k, t, DIM == 5);
-            out[j] = fast_phase2<VARIANT, DIM>(t, mode);
+            float u1[5], u2[5];
+            int j = queue_load<DIM>(queues[w], k, u1, u2);
+            out[j] = fast_finish<VARIANT, DIM>(u1, u2, mode, edge);
         }
     }
 }
