@@ -106,8 +106,8 @@ def main():
     n = args.pairs
     b1 = make_boxes(n, 2 * rank, dev)        # rank r owns its own contiguous shard, generated per rank
     b2 = make_boxes(n, 2 * rank + 1, dev)
-    gathered = torch.empty(world * n, dtype=torch.float32, device=dev)
-    shard = gathered[rank * n:(rank + 1) * n]  # the kernel writes straight into its slot of the gathered vector
+    gathered = torch.empty(world * n, dtype=torch.float32, device=dev) if world > 1 else None
+    shard = torch.empty(n, dtype=torch.float32, device=dev)   # this rank's IoU vector (pre-allocated)
     lib = _lib.lib()
     stream = torch.cuda.current_stream(dev)
     G.set_arithmetic(args.arithmetic)

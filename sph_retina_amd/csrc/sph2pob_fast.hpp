@@ -155,31 +155,34 @@ SPH_DEV float edges_inside3(float px, float py, float c, float s, float ic, floa
 struct FastRec { float N, D, Np, Dp, C, wg, hg, wp, hp, ga, gb; };
 enum : int { FAST_ZERO = 0, FAST_SURVIVOR = 1 };
 
-// Stage 0 (cull): spherical jitter + a conservative bounding-circle test with hardware trig.  Returns true when the
+// Stage 0 (cull): a conservative bounding-circle test with hardware trig on the raw boxes.  Returns true when the
 // pair's IoU is exactly 0 (the two planar rectangles' circumscribed circles cannot touch, whatever the rounding of
 // the accurate path: the bound carries 1.5e-3 rad for both jitters + the reference's own rounding of A, and 1e-4 in
-// cos-space for the hardware trig's error).  j1/j2 receive the jittered boxes (degrees) for the later stages.
+// cos-space for the hardware trig's error).
 template <int DIM>
-SPH_DEV bool fast_cull(const float (&in1)[5], const float (&in2)[5], int edge, float (&j1)[5], float (&j2)[5]) {
+SPH_DEV bool fast_cull(const float (&in1)[5], const float (&in2)[5], int edge) {
 #pragma clang fp contract(fast)
-#pragma unroll
-    for (int k = 0; k < 5; k++) { j1[k] = in1[k]; j2[k] = in2[k]; }
-    jitter_spherical<DIM>(j1, j2);
-    float wg = j1[2] * kDeg2Rad, hg = j1[3] * kDeg2Rad, wp = j2[2] * kDeg2Rad, hp = j2[3] * kDeg2Rad;
+    // raw (un-jittered) boxes: the spherical jitter moves every coordinate by at most 2.5e-4 deg (4.3e-6 rad) and the
+    // clamps only shrink extents; both are far inside the 1.5e-3 rad margin.  Extents are clamped to the jitter's
+    // upper bound (180 deg) so that an out-of-range alpha/beta cannot under-estimate R.
+    float wg = fminf(in1[2], 180.0f) * kDeg2Rad, hg = fminf(in1[3], 180.0f) * kDeg2Rad;
+    float wp = fminf(in2[2], 180.0f) * kDeg2Rad, hp = fminf(in2[3], 180.0f) * kDeg2Rad;
     if (edge != EDGE_ARC) {
         wg = edge_length(wg, edge); hg = edge_length(hg, edge); wp = edge_length(wp, edge); hp = edge_length(hp, edge);
     }
     float d1 = wg * wg + hg * hg, d2 = wp * wp + hp * hp;
     float R = 0.5f * (d1 * fast_rsq(d1) + d2 * fast_rsq(d2)) + 1.5e-3f;
-    if (!(R < 3.0f)) return false;
     float R2 = R * R;
     float cosR_lb = fmaf(fmaf(fmaf(-1.0f / 720.0f, R2, 1.0f / 24.0f), R2, -0.5f), R2, 1.0f);  // <= cos R
     const float kRev = 1.0f / 360.0f;
-    float sg = hw_sin_rev(j1[1] * kRev), cg = hw_cos_rev(j1[1] * kRev);
-    float sp = hw_sin_rev(j2[1] * kRev), cp = hw_cos_rev(j2[1] * kRev);
-    float cD = hw_cos_rev((j2[0] - j1[0]) * kRev);
+    // phi is clamped into [0, 180] by the jitter; theta enters only through cos(theta_p - theta_g) (periodic)
+    float phg = fminf(fmaxf(in1[1], 0.0f), 180.0f) * kRev, php = fminf(fmaxf(in2[1], 0.0f), 180.0f) * kRev;
+    float thg = fminf(fmaxf(in1[0], 0.0f), 360.0f), thp = fminf(fmaxf(in2[0], 0.0f), 360.0f);
+    float sg = hw_sin_rev(phg), cg = hw_cos_rev(phg);
+    float sp = hw_sin_rev(php), cp = hw_cos_rev(php);
+    float cD = hw_cos_rev((thp - thg) * kRev);
     float C = cg * cp + sg * sp * cD;
-    return C < cosR_lb - 1e-4f;
+    return (R < 3.0f) & (C < cosR_lb - 1e-4f) & (d1 > 0.0f) & (d2 > 0.0f);
 }
 
 // Stage 1: accurate trig on the jittered boxes, bearing numerators, and the exact early-out on accurate values.
@@ -310,13 +313,19 @@ SPH_DEV float fast_phase2(const FastRec& r, int mode) {
     float inter = 0.5f * fmaxf(t2, 0.0f);
     float a1 = wg * hg, a2 = wp * hp;
     float base = mode == MODE_IOU ? (a1 + a2 - inter) : a1;
-    float iou = inter / base;
+    float rb = fast_rcp(base);
+    rb = rb * (2.0f - base * rb);  // one Newton step: ~0.5 ulp quotient without the IEEE divide expansion
+    float iou = inter * rb;
     return fminf(fmaxf(iou, 0.0f), 1.0f);
 }
 
-// Stages 1 + 2 on jittered boxes.
+// Spherical jitter + stages 1 + 2 for a pair that survived the cull.
 template <int VARIANT, int DIM>
-SPH_DEV float fast_finish(const float (&j1)[5], const float (&j2)[5], int mode, int edge) {
+SPH_DEV float fast_finish(const float (&in1)[5], const float (&in2)[5], int mode, int edge) {
+    float j1[5], j2[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) { j1[k] = in1[k]; j2[k] = in2[k]; }
+    jitter_spherical<DIM>(j1, j2);
     FastRec r;
     if (fast_phase1<VARIANT, DIM>(j1, j2, edge, r) == FAST_ZERO) return 0.0f;
     return fast_phase2<VARIANT, DIM>(r, mode);
@@ -325,9 +334,8 @@ SPH_DEV float fast_finish(const float (&j1)[5], const float (&j2)[5], int mode, 
 // VARIANT: 0 standard, 1 efficient.  Returns clamp(IoU, 0, 1) of one pair.
 template <int VARIANT, int DIM>
 SPH_DEV float pair_iou_fast(const float (&in1)[5], const float (&in2)[5], int mode, int edge) {
-    float j1[5], j2[5];
-    if (fast_cull<DIM>(in1, in2, edge, j1, j2)) return 0.0f;
-    return fast_finish<VARIANT, DIM>(j1, j2, mode, edge);
+    if (fast_cull<DIM>(in1, in2, edge)) return 0.0f;
+    return fast_finish<VARIANT, DIM>(in1, in2, mode, edge);
 }
 
 }  // namespace sph2pob

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_kernel(const float* __rest
 // when 64 records are available, i.e. on fully populated waves.  Leftovers of the 4 waves of a workgroup are
 // merged once at the end.  Stores: culled pairs write 0 from phase 1, survivors write from phase 2 by index.
 constexpr int kQCap = 128;                    // per-wave stack capacity (<= 63 carried + 64 pushed)
-constexpr int kQFields = 10;                  // jittered (theta, phi, alpha, beta[, gamma]) of both boxes
+constexpr int kQFields = 10;                  // raw (theta, phi, alpha, beta[, gamma]) of both boxes
 
 struct WaveQueue {
     float f[kQFields][kQCap];
@@ -113,13 +113,12 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_compact_kernel(const float
             load_box<DIM>(b2, i, y);
         }
         bool surv = false;
-        float j1[5], j2[5];
         if (i < n) {
-            if (fast_cull<DIM>(x, y, edge, j1, j2)) out[i] = 0.0f;
+            if (fast_cull<DIM>(x, y, edge)) out[i] = 0.0f;
             else surv = true;
         }
         const unsigned long long m = __ballot(surv);
-        if (surv) queue_store<DIM>(q, count + __popcll(m & ((1ull << lane) - 1ull)), j1, j2, i);
+        if (surv) queue_store<DIM>(q, count + __popcll(m & ((1ull << lane) - 1ull)), x, y, i);
         count += __popcll(m);
         if (count >= 64) {  // wave-uniform
             count -= 64;

@@ -1,0 +1,115 @@
+"""GPU box: time BASELINE.json configs[2] (Sph2Pob + CIoU loss fwd+bwd, 1M RBFoV) and configs[3] (MaxIoUAssigner
+overlaps 64 GT x ~98k anchors + SphNMS on 5000 boxes / 37 classes) on one MI355X.  One JSON line per config."""
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sph_retina_amd as S  # noqa: E402
+from sph_retina_amd.losses import Sph2PobIoULoss  # noqa: E402
+from sph_retina_amd.bbox.nms import SphNMS  # noqa: E402
+
+
+def timeit(fn, warm=5, reps=30):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def boxes(n, seed, dim=4, alpha=(1, 100), gamma=(-90, 90)):
+    g = torch.Generator().manual_seed(seed)
+    u = torch.rand((n, 5), generator=g)
+    cols = [u[:, 0] * 360, u[:, 1] * 180, u[:, 2] * (alpha[1] - alpha[0]) + alpha[0],
+            u[:, 3] * (alpha[1] - alpha[0]) + alpha[0]]
+    if dim == 5:
+        cols.append(u[:, 4] * (gamma[1] - gamma[0]) + gamma[0])
+    return torch.stack(cols, 1).cuda()
+
+
+def config3(n=1_000_000):
+    tgt = boxes(n, 0, 5, alpha=(5, 90), gamma=(-60, 60))
+    g = torch.Generator().manual_seed(1)
+    pred = tgt + (torch.randn((n, 5), generator=g) * torch.tensor([8., 8., 6., 6., 10.])).cuda()
+    pred[:, 0] %= 360
+    pred[:, 1].clamp_(1, 179)
+    pred[:, 2:4].clamp_(1, 170)
+    pred.requires_grad_(True)
+    loss = Sph2PobIoULoss(mode='ciou', reduction='mean')
+
+    def step():
+        pred.grad = None
+        loss(pred, tgt).backward()
+    t = timeit(step)
+    tf = timeit(lambda: loss(pred.detach(), tgt))
+    return {'config': 'configs[2]: 1,000,000 RBFoV pairs, Sph2Pob + CIoU loss forward+backward', 'pairs': n,
+            'fwd_bwd_ms': t * 1e3, 'fwd_ms': tf * 1e3, 'pairs_per_s_fwd_bwd': n / t,
+            'algorithmic_bytes_per_pair': 108, 'hbm_GBps': 108 * n / t / 1e9, 'hbm_frac_of_8TBps': 108 * n / t / 8e12}
+
+
+def retina_anchors(h=512, w=1024):
+    """5-level, 9-anchor RetinaNet grid (strides 8..128, octave_base_scale 4, 3 scales x 3 ratios) mapped pixel->sph
+    as sphdet/bbox/box_formator.py:85-92: (x/W*360, y/H*180, w/W*360, h/H*180)."""
+    out = []
+    for stride in (8, 16, 32, 64, 128):
+        fh, fw = math.ceil(h / stride), math.ceil(w / stride)
+        ys, xs = torch.meshgrid(torch.arange(fh) * stride, torch.arange(fw) * stride, indexing='ij')
+        for sc in (2 ** 0, 2 ** (1 / 3), 2 ** (2 / 3)):
+            for ratio in (0.5, 1.0, 2.0):
+                size = 4 * stride * sc
+                ww, hh = size / math.sqrt(ratio), size * math.sqrt(ratio)
+                out.append(torch.stack([xs.flatten() / w * 360, ys.flatten() / h * 180,
+                                        torch.full((fh * fw,), ww / w * 360), torch.full((fh * fw,), hh / h * 180)], 1))
+    a = torch.cat(out).float()
+    a[:, 1].clamp_(0.5, 179.5)
+    return a.cuda()
+
+
+def config4():
+    anchors = retina_anchors()
+    g = torch.Generator().manual_seed(0)
+    u = torch.rand((64, 4), generator=g)
+    gt = torch.stack([u[:, 0] * 360, 20 + u[:, 1] * 140, 5 + u[:, 2] * 85, 5 + u[:, 3] * 85], 1).cuda()
+    calc = S.SphOverlaps2D(backend='sph2pob_standard_iou', box_version=4)
+    t_iou = timeit(lambda: calc(gt, anchors))
+    ov = calc(gt, anchors)
+
+    def assign():
+        o = calc(gt, anchors)
+        mx, am = o.max(dim=0)
+        gmx, gam = o.max(dim=1)
+        return mx, am, gmx, gam
+    t_assign = timeit(assign)
+    k = 5000
+    rng = np.random.default_rng(4)
+    centres = boxes(300, 8, alpha=(5, 60)).cpu().numpy()
+    b = centres[rng.integers(0, 300, k)] + rng.standard_normal((k, 4)).astype(np.float32) * 2.0
+    b[:, 0] %= 360
+    b[:, 1] = b[:, 1].clip(1, 179)
+    b[:, 2:] = b[:, 2:].clip(2, 120)
+    nb, ns, ni = torch.from_numpy(b).cuda(), torch.rand(k).cuda(), torch.randint(0, 37, (k,)).cuda()
+    nms = SphNMS('sph2pob_efficient')
+    cfg = dict(type='nms', iou_threshold=0.5, max_num=100)
+    t_nms = timeit(lambda: nms(nb, ns, ni, cfg), reps=20)
+    t_nms1 = timeit(lambda: nms(nb, ns, torch.zeros_like(ni), cfg), reps=10)
+    m, n = ov.shape
+    return {'config': 'configs[3]: MaxIoUAssigner overlaps 64 GT x %d anchors (512x1024 ERP grid) + SphNMS 5000 boxes' % n,
+            'pairs': m * n, 'iou_matrix_ms': t_iou * 1e3, 'pairs_per_s': m * n / t_iou,
+            'iou_plus_max_argmax_ms': t_assign * 1e3, 'frac_pairs_overlapping': float((ov > 0).float().mean()),
+            'nms_5000x37cls_ms': t_nms * 1e3, 'nms_5000_single_class_ms': t_nms1 * 1e3}
+
+
+if __name__ == '__main__':
+    for fn in (config3, config4):
+        print(json.dumps(fn()), flush=True)
