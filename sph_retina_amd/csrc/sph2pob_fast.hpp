@@ -159,30 +159,41 @@ enum : int { FAST_ZERO = 0, FAST_SURVIVOR = 1 };
 // pair's IoU is exactly 0 (the two planar rectangles' circumscribed circles cannot touch, whatever the rounding of
 // the accurate path: the bound carries 1.5e-3 rad for both jitters + the reference's own rounding of A, and 1e-4 in
 // cos-space for the hardware trig's error).
+// Per-box part of the cull: hardware sin/cos of the colatitude, longitude in revolutions, circumscribed-circle
+// radius of the planar rectangle (+inf for a degenerate box so that it is never culled).
+struct CullBox { float s, c, th_rev, r; };
+SPH_DEV CullBox cull_box(const float (&b)[5], int edge) {
+#pragma clang fp contract(fast)
+    // raw (un-jittered) box: the spherical jitter moves every coordinate by at most 2.5e-4 deg (4.3e-6 rad) and the
+    // clamps only shrink extents; both are far inside the 1.5e-3 rad margin.  Extents are clamped to the jitter's
+    // upper bound (180 deg) so that an out-of-range alpha/beta cannot under-estimate the radius; phi is clamped
+    // into [0, 180] like the jitter does; theta enters only through cos(theta_p - theta_g) (periodic).
+    float w = fminf(b[2], 180.0f) * kDeg2Rad, h = fminf(b[3], 180.0f) * kDeg2Rad;
+    if (edge != EDGE_ARC) { w = edge_length(w, edge); h = edge_length(h, edge); }
+    float d = w * w + h * h;
+    const float kRev = 1.0f / 360.0f;
+    float ph = fminf(fmaxf(b[1], 0.0f), 180.0f) * kRev;
+    CullBox cb;
+    cb.s = hw_sin_rev(ph);
+    cb.c = hw_cos_rev(ph);
+    cb.th_rev = fminf(fmaxf(b[0], 0.0f), 360.0f) * kRev;
+    cb.r = d > 0.0f ? 0.5f * d * fast_rsq(d) : __builtin_inff();
+    return cb;
+}
+// Per-pair part: true when the circumscribed circles cannot touch (IoU exactly 0).  1 - R^2/2 + R^4/24 - R^6/720
+// <= cos R; margins: 1.5e-3 rad for both jitters + the reference's rounding of A, 1e-4 in cos-space for the
+// hardware trig.
+SPH_DEV bool cull_pair(const CullBox& g, const CullBox& p) {
+#pragma clang fp contract(fast)
+    float R = (g.r + p.r) + 1.5e-3f;
+    float R2 = R * R;
+    float cosR_lb = fmaf(fmaf(fmaf(-1.0f / 720.0f, R2, 1.0f / 24.0f), R2, -0.5f), R2, 1.0f);
+    float C = g.c * p.c + (g.s * p.s) * hw_cos_rev(p.th_rev - g.th_rev);
+    return (R < 3.0f) & (C < cosR_lb - 1e-4f);
+}
 template <int DIM>
 SPH_DEV bool fast_cull(const float (&in1)[5], const float (&in2)[5], int edge) {
-#pragma clang fp contract(fast)
-    // raw (un-jittered) boxes: the spherical jitter moves every coordinate by at most 2.5e-4 deg (4.3e-6 rad) and the
-    // clamps only shrink extents; both are far inside the 1.5e-3 rad margin.  Extents are clamped to the jitter's
-    // upper bound (180 deg) so that an out-of-range alpha/beta cannot under-estimate R.
-    float wg = fminf(in1[2], 180.0f) * kDeg2Rad, hg = fminf(in1[3], 180.0f) * kDeg2Rad;
-    float wp = fminf(in2[2], 180.0f) * kDeg2Rad, hp = fminf(in2[3], 180.0f) * kDeg2Rad;
-    if (edge != EDGE_ARC) {
-        wg = edge_length(wg, edge); hg = edge_length(hg, edge); wp = edge_length(wp, edge); hp = edge_length(hp, edge);
-    }
-    float d1 = wg * wg + hg * hg, d2 = wp * wp + hp * hp;
-    float R = 0.5f * (d1 * fast_rsq(d1) + d2 * fast_rsq(d2)) + 1.5e-3f;
-    float R2 = R * R;
-    float cosR_lb = fmaf(fmaf(fmaf(-1.0f / 720.0f, R2, 1.0f / 24.0f), R2, -0.5f), R2, 1.0f);  // <= cos R
-    const float kRev = 1.0f / 360.0f;
-    // phi is clamped into [0, 180] by the jitter; theta enters only through cos(theta_p - theta_g) (periodic)
-    float phg = fminf(fmaxf(in1[1], 0.0f), 180.0f) * kRev, php = fminf(fmaxf(in2[1], 0.0f), 180.0f) * kRev;
-    float thg = fminf(fmaxf(in1[0], 0.0f), 360.0f), thp = fminf(fmaxf(in2[0], 0.0f), 360.0f);
-    float sg = hw_sin_rev(phg), cg = hw_cos_rev(phg);
-    float sp = hw_sin_rev(php), cp = hw_cos_rev(php);
-    float cD = hw_cos_rev((thp - thg) * kRev);
-    float C = cg * cp + sg * sp * cD;
-    return (R < 3.0f) & (C < cosR_lb - 1e-4f) & (d1 > 0.0f) & (d2 > 0.0f);
+    return cull_pair(cull_box(in1, edge), cull_box(in2, edge));
 }
 
 // Stage 1: accurate trig on the jittered boxes, bearing numerators, and the exact early-out on accurate values.

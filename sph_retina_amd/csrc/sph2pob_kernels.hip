@@ -18,6 +18,7 @@ constexpr int kBlock = 256;  // 4 waves of 64 lanes
 // SPH2POB_SLICES_PER_WAVE sets how many 64-pair slices each wave of the compacting kernel walks
 static bool g_no_compact = getenv("SPH2POB_NO_COMPACT") != nullptr;
 static bool g_prefetch = getenv("SPH2POB_NO_PREFETCH") == nullptr;
+static int g_pw_rows = getenv("SPH2POB_PW_ROWS") ? atoi(getenv("SPH2POB_PW_ROWS")) : 0;
 static int g_slices_per_wave = getenv("SPH2POB_SLICES_PER_WAVE") ? atoi(getenv("SPH2POB_SLICES_PER_WAVE")) : 4;
 
 template <int DIM>
@@ -144,6 +145,67 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_compact_kernel(const float
             out[j] = fast_finish<VARIANT, DIM>(u1, u2, mode, edge);
         }
     }
+}
+
+// ---- pairwise IoU for the assigner call pattern (few rows x many columns), closed-form core ----
+// One thread owns one column box (anchor); a workgroup covers 256 columns x up to 64 rows (GT).  Per-box cull
+// quantities are hoisted: rows live in LDS (broadcast reads), the column's in registers, so a culled pair costs
+// ~15 VALU instructions + one coalesced store of 0.  Survivors are (row, column) index pairs pushed on the wave's
+// LDS stack and finished 64 at a time on fully populated waves (same scheme as iou_aligned_compact_kernel).
+constexpr int kPwRows = 64;
+template <int VARIANT, int DIM>
+__global__ __launch_bounds__(kBlock) void iou_pairwise_compact_kernel(const float* __restrict__ b1, int m,
+                                                                     const float* __restrict__ b2, int n,
+                                                                     float* __restrict__ out, int mode, int edge,
+                                                                     int rows_per_wg) {
+    __shared__ float row_raw[kPwRows][5];
+    __shared__ float4 row_cull[kPwRows];
+    __shared__ int2 stack[kBlock / 64][kQCap];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_wg, rows = (m - r0 < rows_per_wg) ? m - r0 : rows_per_wg;
+    if ((int)threadIdx.x < rows) {
+        float g[5];
+        load_box<DIM>(b1, r0 + threadIdx.x, g);
+        CullBox cg = cull_box(g, edge);
+#pragma unroll
+        for (int k = 0; k < 5; k++) row_raw[threadIdx.x][k] = g[k];
+        row_cull[threadIdx.x] = make_float4(cg.s, cg.c, cg.th_rev, cg.r);
+    }
+    __syncthreads();
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = j < n;
+    float a[5] = {0.0f, 0.0f, 1.0f, 1.0f, 0.0f};
+    if (valid) load_box<DIM>(b2, j, a);
+    const CullBox ca = cull_box(a, edge);
+    int2* st = stack[wave];
+    int count = 0;
+    auto finish_one = [&](int2 e) {
+        float g[5], p[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) g[k] = row_raw[e.x][k];
+        load_box<DIM>(b2, e.y, p);
+        out[(int64_t)(r0 + e.x) * n + e.y] = fast_finish<VARIANT, DIM>(g, p, mode, edge);
+    };
+    for (int i = 0; i < rows; i++) {
+        const float4 rc = row_cull[i];
+        bool surv = false;
+        if (valid) {
+            if (cull_pair(CullBox{rc.x, rc.y, rc.z, rc.w}, ca)) out[(int64_t)(r0 + i) * n + j] = 0.0f;
+            else surv = true;
+        }
+        const unsigned long long mk = __ballot(surv);
+        if (surv) st[count + __popcll(mk & ((1ull << lane) - 1ull))] = make_int2(i, j);
+        count += __popcll(mk);
+        if (count >= 64) {
+            count -= 64;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            finish_one(st[count + lane]);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < count) finish_one(st[lane]);
 }
 
 // out[i*n + j]: consecutive lanes walk j (coalesced stores, b2 loads coalesced, b1 row is a broadcast).
@@ -279,31 +341,38 @@ template <int VARIANT, int DIM, bool FAST>
 __global__ __launch_bounds__(kBlock) void nms_mask_kernel(const float* __restrict__ boxes,
                                                          const int64_t* __restrict__ cls, int64_t k, int words,
                                                          float thr, unsigned long long* __restrict__ mask) {
+    // one wave per row i: only the words that hold later columns of row i's own class segment are evaluated
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int w = blockIdx.x * (kBlock / 64) + wave;
-    const int64_t i = blockIdx.y;
-    if (w >= words) return;
-    const int64_t j0 = (int64_t)w * 64, j1 = (j0 + 63 < k - 1) ? j0 + 63 : k - 1;
-    bool skip = j1 <= i;
-    int64_t ci = 0;
-    if (cls && !skip) {
-        ci = cls[i];
-        skip = cls[j1] < ci || cls[j0 > i ? j0 : i] > ci;  // sorted by class: no column of this word shares row i's class
+    const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + wave;
+    if (i >= k) return;
+    int64_t seg_end = k;  // first index past row i's class segment (boxes are sorted by class)
+    if (cls) {
+        const int64_t ci = cls[i];
+        int64_t lo = i + 1, hi = k;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if (cls[mid] <= ci) lo = mid + 1; else hi = mid;
+        }
+        seg_end = lo;
     }
-    if (skip) {  // wave-uniform
-        if (lane == 0) mask[i * words + w] = 0ull;
-        return;
+    const int w_first = (int)((i + 1) >> 6), w_last = (int)((seg_end - 1) >> 6);  // empty when seg_end == i + 1
+    unsigned long long* row = mask + i * words;
+    for (int w = lane; w < words; w += 64)
+        if (w < w_first || w > w_last || seg_end <= i + 1) row[w] = 0ull;
+    if (seg_end <= i + 1) return;
+    float x[5];
+    load_box<DIM>(boxes, i, x);
+    for (int w = w_first; w <= w_last; w++) {
+        const int64_t j = (int64_t)w * 64 + lane;
+        bool hit = false;
+        if (j > i && j < seg_end) {
+            float y[5];
+            load_box<DIM>(boxes, j, y);
+            hit = pair_iou_sel<VARIANT, DIM, FAST>(x, y, MODE_IOU, EDGE_ARC, ANGLE_EQUATOR) > thr;
+        }
+        unsigned long long bits = __ballot(hit);
+        if (lane == 0) row[w] = bits;
     }
-    const int64_t j = j0 + lane;
-    bool hit = false;
-    if (j < k && j > i && (!cls || cls[j] == ci)) {
-        float x[5], y[5];
-        load_box<DIM>(boxes, i, x);
-        load_box<DIM>(boxes, j, y);
-        hit = pair_iou_sel<VARIANT, DIM, FAST>(x, y, MODE_IOU, EDGE_ARC, ANGLE_EQUATOR) > thr;
-    }
-    unsigned long long bits = __ballot(hit);
-    if (lane == 0) mask[i * words + w] = bits;
 }
 
 constexpr int kNmsMaxWords = 512;  // K <= 32768 boxes per call
@@ -315,27 +384,37 @@ __global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long*
     for (int w = lane; w < words; w += 64) removed[w] = 0ull;
     __syncthreads();
     for (int b = 0; b < words; b++) {
-        const int64_t row = (int64_t)b * 64 + lane;
-        unsigned long long diag = row < k ? mask[row * words + b] : 0ull;
-        unsigned long long rem = removed[b];
-        const int nrow = (k - (int64_t)b * 64 < 64) ? (int)(k - (int64_t)b * 64) : 64;
+        const int64_t row0 = (int64_t)b * 64, row = row0 + lane;
+        const unsigned long long diag = row < k ? mask[row * words + b] : 0ull;
+        const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+        const unsigned long long rem_v = removed[b];
+        // scalar (SGPR) state for the serial chain: rem, keepbits
+        // (the readlane/readfirstlane builtins return int: cast before widening, or bit 31 sign-extends)
+        unsigned long long rem = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(rem_v >> 32)) << 32) |
+                                 (unsigned)__builtin_amdgcn_readfirstlane((unsigned)rem_v);
+        const int nrow = (k - row0 < 64) ? (int)(k - row0) : 64;
         unsigned long long keepbits = 0ull;
-        for (int r = 0; r < nrow; r++) {  // wave-uniform serial chain: registers only
-            unsigned lo = __builtin_amdgcn_readlane((unsigned)(diag & 0xffffffffull), r);
-            unsigned hi = __builtin_amdgcn_readlane((unsigned)(diag >> 32), r);
+        for (int r = 0; r < nrow; r++) {
             if (!((rem >> r) & 1ull)) {
                 keepbits |= 1ull << r;
-                rem |= ((unsigned long long)hi << 32) | lo;
+                rem |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, r) << 32) |
+                       (unsigned)__builtin_amdgcn_readlane(dlo, r);
             }
         }
         if (row < k) keep[row] = (unsigned char)((keepbits >> lane) & 1ull);
-        // OR the kept rows of this block into the later words of the removed vector
+        // OR the kept rows into the later words; lanes own words, loads of 16 rows are issued back to back
         for (int w = b + 1 + lane; w < words; w += 64) {
-            unsigned long long acc = 0ull, kb = keepbits;
-            while (kb) {
-                int r = __builtin_ctzll(kb);
-                kb &= kb - 1;
-                acc |= mask[((int64_t)b * 64 + r) * words + w];
+            const unsigned long long* col = mask + row0 * words + w;
+            unsigned long long acc = 0ull;
+            for (int r0 = 0; r0 < nrow; r0 += 16) {
+                unsigned long long v[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const int r = r0 + u;
+                    v[u] = (r < nrow && ((keepbits >> r) & 1ull)) ? col[(int64_t)r * words] : 0ull;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; u++) acc |= v[u];
             }
             removed[w] |= acc;
         }
@@ -391,6 +470,20 @@ struct AlignedLaunch {
 struct PairwiseLaunch {
     const float* b1; int64_t m; const float* b2; int64_t n; float* out; int mode, edge, angle; hipStream_t s; bool fast = true;
     template <int V, int D> int run() {
+        if (fast && V != 2 && angle == SPH2POB_ANGLE_EQUATOR && n < ((int64_t)1 << 31) - kBlock && m <= (int64_t)65535 * 4 &&
+            !g_no_compact) {
+            // rows per workgroup: as many as possible (amortises the per-column setup, fills the survivor stacks) while
+            // the grid still holds >= ~8 workgroups per CU
+            const int64_t col_tiles = (n + kBlock - 1) / kBlock;
+            int64_t rpw = g_pw_rows > 0 ? g_pw_rows : (m * col_tiles) / 3072;
+            if (rpw < 4) rpw = 4;
+            if (rpw > kPwRows) rpw = kPwRows;
+            if (rpw > m) rpw = m;
+            dim3 grid((unsigned)col_tiles, (unsigned)((m + rpw - 1) / rpw));
+            hipLaunchKernelGGL((iou_pairwise_compact_kernel<V == 2 ? 0 : V, D>), grid, dim3(kBlock), 0, s, b1, (int)m, b2, (int)n,
+                               out, mode, edge, (int)rpw);
+            return launch_status();
+        }
         // grid.y is limited to 65535 rows per launch: walk the rows in slabs
         const int64_t kMaxRows = 65535;
         for (int64_t r0 = 0; r0 < m; r0 += kMaxRows) {
@@ -540,7 +633,7 @@ int sph2pob_nms_f32(const float* boxes_sorted, const int64_t* cls_sorted, int64_
     const int words = (int)((k + 63) / 64);
     unsigned long long* mask = (unsigned long long*)workspace;
     const int wpb = kBlock / 64;
-    dim3 grid((unsigned)((words + wpb - 1) / wpb), (unsigned)k);
+    dim3 grid((unsigned)((k + wpb - 1) / wpb));
 #define SPH_NMS_LAUNCH(V, D, F) \
     hipLaunchKernelGGL((nms_mask_kernel<V, D, F>), grid, dim3(kBlock), 0, s, boxes_sorted, cls_sorted, k, words, iou_threshold, mask)
     if (variant == SPH2POB_VARIANT_EFFICIENT) {
