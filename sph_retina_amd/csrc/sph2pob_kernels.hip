@@ -377,48 +377,70 @@ __global__ __launch_bounds__(kBlock) void nms_mask_kernel(const float* __restric
 
 constexpr int kNmsMaxWords = 512;  // K <= 32768 boxes per call
 
-__global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long* __restrict__ mask, int64_t k,
-                                                       int words, unsigned char* __restrict__ keep) {
-    __shared__ unsigned long long removed[kNmsMaxWords];
-    const int lane = threadIdx.x;
-    for (int w = lane; w < words; w += 64) removed[w] = 0ull;
-    __syncthreads();
-    for (int b = 0; b < words; b++) {
+// Greedy sweep, one wave per CLASS SEGMENT (classes are independent): every wave looks at one row; only the first row
+// of a segment survives and sweeps that segment's 64-row blocks in order.  Inside a block the serial dependency is
+// resolved on the 64x64 diagonal block held one row per lane (v_readlane + scalar bit operations only); the kept
+// rows are then OR-ed into the wave's "removed" bit-vector (LDS) with lanes owning words and 16 row loads in flight.
+__global__ __launch_bounds__(kBlock) void nms_sweep_kernel(const unsigned long long* __restrict__ mask,
+                                                           const int64_t* __restrict__ cls, int64_t k, int words,
+                                                           unsigned char* __restrict__ keep) {
+    __shared__ unsigned long long removed_all[kBlock / 64][kNmsMaxWords];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t s = (int64_t)blockIdx.x * (kBlock / 64) + wave;  // candidate segment head
+    if (s >= k) return;
+    if (cls ? (s > 0 && cls[s] == cls[s - 1]) : (s > 0)) return;
+    int64_t seg_end = k;
+    if (cls) {
+        const int64_t cs = cls[s];
+        int64_t lo = s + 1, hi = k;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if (cls[mid] <= cs) lo = mid + 1; else hi = mid;
+        }
+        seg_end = lo;
+    }
+    unsigned long long* removed = removed_all[wave];
+    const int b_first = (int)(s >> 6), b_last = (int)((seg_end - 1) >> 6);
+    for (int w = b_first + lane; w <= b_last; w += 64) removed[w] = 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int b = b_first; b <= b_last; b++) {
         const int64_t row0 = (int64_t)b * 64, row = row0 + lane;
-        const unsigned long long diag = row < k ? mask[row * words + b] : 0ull;
+        const bool mine = row >= s && row < seg_end;
+        const unsigned long long diag = mine ? mask[row * words + b] : 0ull;
         const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
         const unsigned long long rem_v = removed[b];
-        // scalar (SGPR) state for the serial chain: rem, keepbits
+        // scalar (SGPR) state of the serial chain; rows of the block outside this segment start out "removed"
         // (the readlane/readfirstlane builtins return int: cast before widening, or bit 31 sign-extends)
         unsigned long long rem = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(rem_v >> 32)) << 32) |
                                  (unsigned)__builtin_amdgcn_readfirstlane((unsigned)rem_v);
-        const int nrow = (k - row0 < 64) ? (int)(k - row0) : 64;
+        rem |= ~__ballot(mine);
         unsigned long long keepbits = 0ull;
-        for (int r = 0; r < nrow; r++) {
+        for (int r = 0; r < 64; r++) {
             if (!((rem >> r) & 1ull)) {
                 keepbits |= 1ull << r;
                 rem |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, r) << 32) |
                        (unsigned)__builtin_amdgcn_readlane(dlo, r);
             }
         }
-        if (row < k) keep[row] = (unsigned char)((keepbits >> lane) & 1ull);
-        // OR the kept rows into the later words; lanes own words, loads of 16 rows are issued back to back
-        for (int w = b + 1 + lane; w < words; w += 64) {
+        if (mine) keep[row] = (unsigned char)((keepbits >> lane) & 1ull);
+        for (int w = b + 1 + lane; w <= b_last; w += 64) {
             const unsigned long long* col = mask + row0 * words + w;
             unsigned long long acc = 0ull;
-            for (int r0 = 0; r0 < nrow; r0 += 16) {
+            for (int r0 = 0; r0 < 64; r0 += 16) {
                 unsigned long long v[16];
 #pragma unroll
                 for (int u = 0; u < 16; u++) {
                     const int r = r0 + u;
-                    v[u] = (r < nrow && ((keepbits >> r) & 1ull)) ? col[(int64_t)r * words] : 0ull;
+                    v[u] = ((keepbits >> r) & 1ull) ? col[(int64_t)r * words] : 0ull;
                 }
 #pragma unroll
                 for (int u = 0; u < 16; u++) acc |= v[u];
             }
             removed[w] |= acc;
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -646,7 +668,7 @@ int sph2pob_nms_f32(const float* boxes_sorted, const int64_t* cls_sorted, int64_
 #undef SPH_NMS_LAUNCH
     int rc = launch_status();
     if (rc) return rc;
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(64), 0, s, mask, k, words, keep);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3((unsigned)((k + wpb - 1) / wpb)), dim3(kBlock), 0, s, mask, cls_sorted, k, words, keep);
     return launch_status();
 }
 
