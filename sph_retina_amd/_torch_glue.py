@@ -58,8 +58,32 @@ def stream_of(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+_FN_CACHE = {}
+
+
 def call(name, device, *args):
     """Enqueue a launcher on the current stream of `device` and translate its return code."""
-    with torch.cuda.device(device):
-        rc = getattr(_lib.lib(), name)(*args)
-    _lib.check(rc, name)
+    fn = _FN_CACHE.get(name)
+    if fn is None:
+        fn = _FN_CACHE[name] = getattr(_lib.lib(), name)
+    if device.index is None or device.index == torch.cuda.current_device():
+        rc = fn(*args)
+    else:
+        with torch.cuda.device(device):
+            rc = fn(*args)
+    if rc:
+        _lib.check(rc, name)
+
+
+_WORKSPACES = {}
+
+
+def sum_workspace(device):
+    """Per-device scratch of the deterministic two-pass sum (stream-ordered reuse is safe: one stream per device
+    in the callers; a different stream gets its own buffer)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        ws = _WORKSPACES[key] = torch.empty((_lib.lib().sph2pob_sum_workspace_floats(),), dtype=torch.float32,
+                                            device=device)
+    return ws

@@ -196,9 +196,12 @@ SPH_DEV bool fast_cull(const float (&in1)[5], const float (&in2)[5], int edge) {
     return cull_pair(cull_box(in1, edge), cull_box(in2, edge));
 }
 
+// trig by-products of stage 1 that the loss adjoint reuses
+struct FastTrig { float sg, cg, sp, cp, sD, cD; };
+
 // Stage 1: accurate trig on the jittered boxes, bearing numerators, and the exact early-out on accurate values.
 template <int VARIANT, int DIM>
-SPH_DEV int fast_phase1(const float (&b1)[5], const float (&b2)[5], int edge, FastRec& r) {
+SPH_DEV int fast_phase1(const float (&b1)[5], const float (&b2)[5], int edge, FastRec& r, FastTrig* trig = nullptr) {
 #pragma clang fp contract(fast)
     // degrees -> radians with the reference's rounding (torch.deg2rad: x * fl32(pi/180))
     float thg = b1[0] * kDeg2Rad, phg = b1[1] * kDeg2Rad, thp = b2[0] * kDeg2Rad, php = b2[1] * kDeg2Rad;
@@ -216,6 +219,7 @@ SPH_DEV int fast_phase1(const float (&b1)[5], const float (&b2)[5], int edge, Fa
     r.N = q - sp * cg * h2;  r.D = -sp * sD;
     r.Np = q + sg * cp * h2; r.Dp = -sg * sD;
     r.C = (cg * cp + sg * sp) - sg * sp * h2;
+    if (trig) { trig->sg = sg; trig->cg = cg; trig->sp = sp; trig->cp = cp; trig->sD = sD; trig->cD = 1.0f - h2; }
     // exact early-out: circumscribed circles of the two planar rectangles cannot touch (margin covers both jitters
     // and the reference's own rounding of A); 1 - R^2/2 + R^4/24 - R^6/720 <= cos R
     float d1 = r.wg * r.wg + r.hg * r.hg, d2 = r.wp * r.wp + r.hp * r.hp;
@@ -226,15 +230,24 @@ SPH_DEV int fast_phase1(const float (&b1)[5], const float (&b2)[5], int edge, Fa
     return FAST_SURVIVOR;
 }
 
-// Phase 2: planar boxes as (cos, sin), rotated jitter, boundary-integral intersection, IoU.
+// The two planar boxes after the rotated jitter, in the frame "P at the origin": T's centre is (dx, dy); angles as
+// (cos, sin).  g_* are gradient gates (false where a clamp / acos floor of the reference is active).
+struct PlanarPair {
+    float dx, dy, ca, sa, cb, sb, wg, hg, wp, hp;
+    bool g_A, g_ag, g_ap, g_wg, g_hg, g_wp, g_hp;
+};
+
+// Phase 2a: planar boxes as (cos, sin) + rotated jitter.
 template <int VARIANT, int DIM>
-SPH_DEV float fast_phase2(const FastRec& r, int mode) {
+SPH_DEV void fast_planar(const FastRec& r, PlanarPair& o) {
 #pragma clang fp contract(fast)
     float wg = r.wg, hg = r.hg, wp = r.wp, hp = r.hp;
     float S2 = r.N * r.N + r.D * r.D;
     float iS = fast_rsq(S2);
     float A = atan2_r(S2 * iS, r.C);
-    A = fmaxf(A, VARIANT == VARIANT_STANDARD ? 2.0f * kMinAng : kMinAng);
+    const float Amin = VARIANT == VARIANT_STANDARD ? 2.0f * kMinAng : kMinAng;
+    o.g_A = A > Amin;
+    A = fmaxf(A, Amin);
     float ca = r.D * iS, sa = r.N * iS, cb = r.Dp * iS, sb = r.Np * iS;
     if (S2 < 1e-13f) {
         // coincident (or exactly antipodal) centres: the bearing is undefined — the reference's own value is
@@ -246,11 +259,18 @@ SPH_DEV float fast_phase2(const FastRec& r, int mode) {
         float sga, cga, sgb, cgb;
         sincos_r(r.ga, sga, cga);
         sincos_r(r.gb, sgb, cgb);
-        if (VARIANT == VARIANT_EFFICIENT) { angle_floor(ca, sa); angle_floor(cb, sb); }  // floor, then a -= gamma
+        if (VARIANT == VARIANT_EFFICIENT) {  // floor, then a -= gamma
+            o.g_ag = fabsf(sa) >= kMinAng; o.g_ap = fabsf(sb) >= kMinAng;
+            angle_floor(ca, sa); angle_floor(cb, sb);
+        }
         rot(ca, sa, cga, -sga);
         rot(cb, sb, cgb, -sgb);
-        if (VARIANT == VARIANT_STANDARD) { angle_floor(ca, sa); angle_floor(cb, sb); }   // d rotated first
+        if (VARIANT == VARIANT_STANDARD) {   // d rotated first
+            o.g_ag = fabsf(sa) >= kMinAng; o.g_ap = fabsf(sb) >= kMinAng;
+            angle_floor(ca, sa); angle_floor(cb, sb);
+        }
     } else {
+        o.g_ag = fabsf(sa) >= kMinAng; o.g_ap = fabsf(sb) >= kMinAng;
         angle_floor(ca, sa);
         angle_floor(cb, sb);
     }
@@ -288,9 +308,9 @@ SPH_DEV float fast_phase2(const FastRec& r, int mode) {
             rot(ca, sa, (float)0.99999923792122, (float)1.2345674864e-3);  // cos/sin(ea)
             rot(cb, sb, (float)0.99999695168547, (float)2.4691330913e-3);  // cos/sin(2ea)
         }
-        c = ca * cb + sa * sb;
-        s = sa * cb - ca * sb;
     }
+    o.g_wg = wg >= (float)(2 * kEpsA / 10); o.g_hg = hg >= (float)(2 * kEpsA / 10);
+    o.g_wp = wp >= (float)(kEpsA / 10);     o.g_hp = hp >= (float)(kEpsA / 10);
     wg = fmaxf(wg, (float)(2 * kEpsA / 10)); hg = fmaxf(hg, (float)(2 * kEpsA / 10));
     wp = fmaxf(wp, (float)(kEpsA / 10));     hp = fmaxf(hp, (float)(kEpsA / 10));
     if (DIM == 5 && (fabsf(r.ga) > 3.1f || fabsf(r.gb) > 3.1f)) {
@@ -307,22 +327,31 @@ SPH_DEV float fast_phase2(const FastRec& r, int mode) {
         if (k1 != a1 || k2 != a2) {
             sincos_r(k1 - twopi * rintf(k1 / twopi), sa, ca);
             sincos_r(k2 - twopi * rintf(k2 / twopi), sb, cb);
-            c = ca * cb + sa * sb;
-            s = sa * cb - ca * sb;
+            o.g_ag &= k1 == a1;
+            o.g_ap &= k2 == a2;
         }
     }
+    o.dx = dx; o.dy = dy; o.ca = ca; o.sa = sa; o.cb = cb; o.sb = sb;
+    o.wg = wg; o.hg = hg; o.wp = wp; o.hp = hp;
+}
 
-    // ---- planar intersection (boundary integral, see sph2pob_device.hpp) ----
+// Phase 2: planar boxes, then boundary-integral intersection and IoU.
+template <int VARIANT, int DIM>
+SPH_DEV float fast_phase2(const FastRec& r, int mode) {
+#pragma clang fp contract(fast)
+    PlanarPair q;
+    fast_planar<VARIANT, DIM>(r, q);
+    float c = q.ca * q.cb + q.sa * q.sb, s = q.sa * q.cb - q.ca * q.sb;
     const float kBig = 1e18f;
     float ic = fminf(fmaxf(fast_rcp(c), -kBig), kBig), is = fminf(fmaxf(fast_rcp(s), -kBig), kBig);
     float aic = fabsf(ic), ais = fabsf(is);
-    float hwa = 0.5f * wg, hha = 0.5f * hg, hwb = 0.5f * wp, hhb = 0.5f * hp;
-    float pax = -(dx * cb + dy * sb), pay = -(dy * cb - dx * sb);
-    float pbx = dx * ca + dy * sa, pby = dy * ca - dx * sa;
-    float t2 = edges_inside3(pax, pay, c, s, ic, is, aic, ais, hwa, hha, hwb, hhb, wg, hg, true) +
-               edges_inside3(pbx, pby, c, -s, ic, -is, aic, ais, hwb, hhb, hwa, hha, wp, hp, false);
+    float hwa = 0.5f * q.wg, hha = 0.5f * q.hg, hwb = 0.5f * q.wp, hhb = 0.5f * q.hp;
+    float pax = -(q.dx * q.cb + q.dy * q.sb), pay = -(q.dy * q.cb - q.dx * q.sb);
+    float pbx = q.dx * q.ca + q.dy * q.sa, pby = q.dy * q.ca - q.dx * q.sa;
+    float t2 = edges_inside3(pax, pay, c, s, ic, is, aic, ais, hwa, hha, hwb, hhb, q.wg, q.hg, true) +
+               edges_inside3(pbx, pby, c, -s, ic, -is, aic, ais, hwb, hhb, hwa, hha, q.wp, q.hp, false);
     float inter = 0.5f * fmaxf(t2, 0.0f);
-    float a1 = wg * hg, a2 = wp * hp;
+    float a1 = q.wg * q.hg, a2 = q.wp * q.hp;
     float base = mode == MODE_IOU ? (a1 + a2 - inter) : a1;
     float rb = fast_rcp(base);
     rb = rb * (2.0f - base * rb);  // one Newton step: ~0.5 ulp quotient without the IEEE divide expansion

@@ -256,7 +256,7 @@ __device__ __forceinline__ float element_weight(const float* __restrict__ w, int
     return s / (float)wd;
 }
 
-template <int DIM>
+template <int DIM, bool FAST>
 __global__ __launch_bounds__(kBlock) void loss_fwd_kernel(const float* __restrict__ pred,
                                                          const float* __restrict__ target,
                                                          const float* __restrict__ weight, int wd,
@@ -268,12 +268,12 @@ __global__ __launch_bounds__(kBlock) void loss_fwd_kernel(const float* __restric
     float x[5], y[5], gx[5], gy[5], io;
     load_box<DIM>(pred, i, x);
     load_box<DIM>(target, i, y);
-    float l = pair_loss<DIM, false>(x, y, loss_mode, eps, &io, gx, gy);
+    float l = pair_loss<DIM, false, FAST>(x, y, loss_mode, eps, &io, gx, gy);
     loss[i] = l * (scale * element_weight<DIM>(weight, wd, i));
     if (iou) iou[i] = io;
 }
 
-template <int DIM>
+template <int DIM, bool FAST>
 __global__ __launch_bounds__(kBlock) void loss_bwd_kernel(const float* __restrict__ pred,
                                                          const float* __restrict__ target,
                                                          const float* __restrict__ weight, int wd,
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kBlock) void loss_bwd_kernel(const float* __restric
     float x[5], y[5], gx[5], gy[5];
     load_box<DIM>(pred, i, x);
     load_box<DIM>(target, i, y);
-    pair_loss<DIM, true>(x, y, loss_mode, eps, nullptr, gx, gy);
+    pair_loss<DIM, true, FAST>(x, y, loss_mode, eps, nullptr, gx, gy);
     float g = grad_out[i * grad_stride] * scale * element_weight<DIM>(weight, wd, i);
     if (DIM == 4) {
         reinterpret_cast<float4*>(gpred)[i] = make_float4(g * gx[0], g * gx[1], g * gx[2], g * gx[3]);
@@ -586,7 +586,10 @@ int sph2pob_transform_f32(const float* b1, const float* b2, float* planar1, floa
 }
 
 int sph2pob_loss_fwd_f32(const float* pred, const float* target, const float* weight, int weight_dim, float scale,
-                         float* loss, float* iou, int64_t n, int box_dim, int loss_mode, float eps, void* stream) {
+                         float* loss, float* iou, int64_t n, int box_dim, int loss_mode_flags, float eps, void* stream) {
+    const int loss_mode = loss_mode_flags & 0xff;
+    const bool fast = !(loss_mode_flags & SPH2POB_FLAG_REFERENCE_ORDER);
+    if (loss_mode_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER)) return SPH2POB_ERR_OPTION;
     if (box_dim != 4 && box_dim != 5) return SPH2POB_ERR_DIM;
     if (loss_mode < 0 || loss_mode > 3) return SPH2POB_ERR_OPTION;
     if (weight && weight_dim != 1 && weight_dim != box_dim) return SPH2POB_ERR_OPTION;
@@ -595,16 +598,20 @@ int sph2pob_loss_fwd_f32(const float* pred, const float* target, const float* we
     if (!pred || !target || !loss) return SPH2POB_ERR_NULL;
     dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
     hipStream_t s = (hipStream_t)stream;
-    if (box_dim == 4)
-        hipLaunchKernelGGL((loss_fwd_kernel<4>), grid, dim3(kBlock), 0, s, pred, target, weight, weight_dim, scale, loss, iou, n, loss_mode, eps);
-    else
-        hipLaunchKernelGGL((loss_fwd_kernel<5>), grid, dim3(kBlock), 0, s, pred, target, weight, weight_dim, scale, loss, iou, n, loss_mode, eps);
+#define SPH_LOSS_FWD(D, F) \
+    hipLaunchKernelGGL((loss_fwd_kernel<D, F>), grid, dim3(kBlock), 0, s, pred, target, weight, weight_dim, scale, loss, iou, n, loss_mode, eps)
+    if (box_dim == 4) { if (fast) SPH_LOSS_FWD(4, true); else SPH_LOSS_FWD(4, false); }
+    else { if (fast) SPH_LOSS_FWD(5, true); else SPH_LOSS_FWD(5, false); }
+#undef SPH_LOSS_FWD
     return launch_status();
 }
 
 int sph2pob_loss_bwd_f32(const float* pred, const float* target, const float* weight, int weight_dim,
                          const float* grad_out, int grad_stride, float scale, float* grad_pred, float* grad_target,
-                         int64_t n, int box_dim, int loss_mode, float eps, void* stream) {
+                         int64_t n, int box_dim, int loss_mode_flags, float eps, void* stream) {
+    const int loss_mode = loss_mode_flags & 0xff;
+    const bool fast = !(loss_mode_flags & SPH2POB_FLAG_REFERENCE_ORDER);
+    if (loss_mode_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER)) return SPH2POB_ERR_OPTION;
     if (box_dim != 4 && box_dim != 5) return SPH2POB_ERR_DIM;
     if (loss_mode < 0 || loss_mode > 3 || (grad_stride != 0 && grad_stride != 1)) return SPH2POB_ERR_OPTION;
     if (weight && weight_dim != 1 && weight_dim != box_dim) return SPH2POB_ERR_OPTION;
@@ -613,10 +620,11 @@ int sph2pob_loss_bwd_f32(const float* pred, const float* target, const float* we
     if (!pred || !target || !grad_out || !grad_pred) return SPH2POB_ERR_NULL;
     dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
     hipStream_t s = (hipStream_t)stream;
-    if (box_dim == 4)
-        hipLaunchKernelGGL((loss_bwd_kernel<4>), grid, dim3(kBlock), 0, s, pred, target, weight, weight_dim, grad_out, grad_stride, scale, grad_pred, grad_target, n, loss_mode, eps);
-    else
-        hipLaunchKernelGGL((loss_bwd_kernel<5>), grid, dim3(kBlock), 0, s, pred, target, weight, weight_dim, grad_out, grad_stride, scale, grad_pred, grad_target, n, loss_mode, eps);
+#define SPH_LOSS_BWD(D, F) \
+    hipLaunchKernelGGL((loss_bwd_kernel<D, F>), grid, dim3(kBlock), 0, s, pred, target, weight, weight_dim, grad_out, grad_stride, scale, grad_pred, grad_target, n, loss_mode, eps)
+    if (box_dim == 4) { if (fast) SPH_LOSS_BWD(4, true); else SPH_LOSS_BWD(4, false); }
+    else { if (fast) SPH_LOSS_BWD(5, true); else SPH_LOSS_BWD(5, false); }
+#undef SPH_LOSS_BWD
     return launch_status();
 }
 

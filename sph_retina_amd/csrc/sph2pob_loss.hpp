@@ -72,22 +72,85 @@ SPH_DEV EdgeSet edges_inside_grad(float pax, float pay, float c, float s, float 
 
 struct PlanarGrad { float x, w, h, a; };  // d(.)/d(x, w, h, a) of one planar box (y never carries gradient)
 
+// What the front end (reference-order or closed-form) hands to the shared loss core: the two planar boxes after the
+// rotated jitter in the frame "pred box at the origin" (target centre = (dx, dy)), gradient gates of every clamp /
+// acos floor on the way, and the trig of the jittered spherical inputs for the chain rule.
+struct LossFront {
+    float dx, dy, ca, sa, cb, sb, wg, hg, wp, hp;
+    bool g_A, g_ag, g_ap, g_wg, g_hg, g_wp, g_hp;
+    float sg, cg, sp, cp, sD, cD;  // sin/cos(phi_g), sin/cos(phi_p), sin/cos(theta_p - theta_g)
+};
+
+// reference-order front end: sph2pob_standard in the reference's fp32 operation order
+template <int DIM>
+SPH_DEV void loss_front_reference(const float (&b1)[5], const float (&b2)[5], LossFront& f) {
+    PBox P, T;
+    transform_standard<DIM>(b1, b2, EDGE_ARC, ANGLE_EQUATOR, P, T);
+    const PBox P0 = P, T0 = T;  // before the rotated jitter: its clamp gates look at these
+    jitter_rotated(P, T);
+    f.dx = T.x - P.x; f.dy = T.y - P.y;
+    f.sa = sinf(P.a); f.ca = cosf(P.a); f.sb = sinf(T.a); f.cb = cosf(T.a);
+    f.wg = P.w; f.hg = P.h; f.wp = T.w; f.hp = T.h;
+    {   // rotated-jitter clamp gates (sph_iou_api.py:237-240: in-place clamp_ => zero gradient outside)
+        const float e = (float)kEpsS, e2 = (float)(2 * kEpsS), e5 = (float)(5 * kEpsS);
+        const float ea = (float)kEpsA, ea2 = (float)(2 * kEpsA);
+        bool similar = (fabsf(P0.x - T0.x) < e) | (fabsf(P0.w - T0.w) < e) | (fabsf(P0.h - T0.h) < e) |
+                       (fabsf(P0.a - T0.a) < e);
+        float pw = P0.w + (similar ? e2 : 0.0f), ph = P0.h + (similar ? e2 : 0.0f), pa = P0.a + (similar ? e : 0.0f);
+        float tw = T0.w + (similar ? e : 0.0f), th = T0.h + (similar ? e : 0.0f), ta = T0.a + (similar ? e5 : 0.0f);
+        if (fabsf(pa - ta) < ea) { pa += ea; ta += ea2; }
+        const double pi = 3.141592653589793;
+        f.g_wg = pw >= (float)(2 * kEpsA / 10); f.g_hg = ph >= (float)(2 * kEpsA / 10);
+        f.g_wp = tw >= (float)(kEpsA / 10);     f.g_hp = th >= (float)(kEpsA / 10);
+        bool in_a = !(pa < (float)(-2 * pi + 2 * kEpsA) || pa > (float)(2 * pi - kEpsA));
+        bool in_b = !(ta < (float)(-2 * pi + kEpsA) || ta > (float)(2 * pi - 2 * kEpsA));
+        // acos(clamp(., -1+1e-7, 1-1e-7)) of compute_internal_angle: zero gradient where the clamp is active
+        f.g_ag = in_a && fabsf(cosf(P0.a)) < kClampHi;
+        f.g_ap = in_b && fabsf(cosf(T0.a)) < kClampHi;
+    }
+    SBox g = load_sbox<DIM>(b1), p = load_sbox<DIM>(b2);
+    f.sg = g.sp; f.cg = g.cp; f.sp = p.sp; f.cp = p.cp;
+    f.cD = p.ct * g.ct + p.st * g.st;
+    f.sD = p.st * g.ct - p.ct * g.st;
+    // x' = +-acos(clamp(cos(A/2))) of compute_spherical_coordinate: gate on A/2 >= acos(1 - 1e-7)
+    float N = f.sp * f.cg * f.cD - f.cp * f.sg, D = -f.sp * f.sD;
+    float C = f.cg * f.cp + f.sg * f.sp * f.cD;
+    f.g_A = atan2f(sqrtf(N * N + D * D), C) > 2.0f * 4.8828125e-4f;
+}
+
+}  // namespace sph2pob
+#include "sph2pob_fast.hpp"
+namespace sph2pob {
+
+// closed-form front end (sph2pob_fast.hpp): same planar boxes, ~4x fewer instructions
+template <int DIM>
+SPH_DEV void loss_front_fast(const float (&b1)[5], const float (&b2)[5], LossFront& f) {
+    FastRec r;
+    FastTrig t;
+    fast_phase1<VARIANT_STANDARD, DIM>(b1, b2, EDGE_ARC, r, &t);
+    PlanarPair q;
+    fast_planar<VARIANT_STANDARD, DIM>(r, q);
+    f.dx = q.dx; f.dy = q.dy; f.ca = q.ca; f.sa = q.sa; f.cb = q.cb; f.sb = q.sb;
+    f.wg = q.wg; f.hg = q.hg; f.wp = q.wp; f.hp = q.hp;
+    f.g_A = q.g_A; f.g_ag = q.g_ag; f.g_ap = q.g_ap; f.g_wg = q.g_wg; f.g_hg = q.g_hg; f.g_wp = q.g_wp; f.g_hp = q.g_hp;
+    f.sg = t.sg; f.cg = t.cg; f.sp = t.sp; f.cp = t.cp; f.sD = t.sD; f.cD = t.cD;
+}
+
 // Per-pair loss element; when BWD, also d(loss)/d(pred[0..DIM)) and d(loss)/d(target[0..DIM)) in 1/degree.
-template <int DIM, bool BWD>
+template <int DIM, bool BWD, bool FAST>
 SPH_DEV float pair_loss(const float (&pred)[5], const float (&target)[5], int loss_mode, float eps, float* iou_out,
                         float (&gpred)[5], float (&gtarget)[5]) {
     float b1[5], b2[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) { b1[k] = pred[k]; b2[k] = target[k]; }
     jitter_spherical<DIM>(b1, b2);
-    PBox P, T;
-    transform_standard<DIM>(b1, b2, EDGE_ARC, ANGLE_EQUATOR, P, T);
-    const PBox P0 = P, T0 = T;  // before the rotated jitter: needed for its clamp gates
-    jitter_rotated(P, T);
+    LossFront f;
+    if (FAST) loss_front_fast<DIM>(b1, b2, f);
+    else loss_front_reference<DIM>(b1, b2, f);
+    const float sa = f.sa, ca = f.ca, sb = f.sb, cb = f.cb, dx = f.dx, dy = f.dy;
+    struct { float x, y, w, h; } P{0.0f, 0.0f, f.wg, f.hg}, T{dx, dy, f.wp, f.hp};
 
     // ---- planar IoU (value of mmcv diff_iou_rotated_2d: sphdet/iou/diff_iou_rotated.py:325-343) ----
-    float sa = sinf(P.a), ca = cosf(P.a), sb = sinf(T.a), cb = cosf(T.a);
-    float dx = T.x - P.x, dy = T.y - P.y;
     float c = ca * cb + sa * sb, s = sa * cb - ca * sb;
     float ic = 1.0f / c, is = 1.0f / s;
     float hwa = 0.5f * P.w, hha = 0.5f * P.h, hwb = 0.5f * T.w, hhb = 0.5f * T.h;
@@ -209,58 +272,40 @@ SPH_DEV float pair_loss(const float (&pred)[5], const float (&target)[5], int lo
         gT.w += LWp * acb + LHp * asb; gT.h += LWp * asb + LHp * acb; gT.a += LWp * dWp_a + LHp * dHp_a;
     }
 
-    // -- rotated-jitter clamp gates (sph_iou_api.py:237-240: in-place clamp_ => zero gradient outside) --
-    {
-        // jitter adds constants first; recompute the pre-clamp values the gates look at
-        const float e = (float)kEpsS, e2 = (float)(2 * kEpsS), e5 = (float)(5 * kEpsS);
-        const float ea = (float)kEpsA, ea2 = (float)(2 * kEpsA);
-        bool similar = (fabsf(P0.x - T0.x) < e) | (fabsf(P0.w - T0.w) < e) | (fabsf(P0.h - T0.h) < e) |
-                       (fabsf(P0.a - T0.a) < e);
-        float pw = P0.w + (similar ? e2 : 0.0f), ph = P0.h + (similar ? e2 : 0.0f), pa = P0.a + (similar ? e : 0.0f);
-        float tw = T0.w + (similar ? e : 0.0f), th = T0.h + (similar ? e : 0.0f), ta = T0.a + (similar ? e5 : 0.0f);
-        if (fabsf(pa - ta) < ea) { pa += ea; ta += ea2; }
-        const double pi = 3.141592653589793;
-        if (pw < (float)(2 * kEpsA / 10)) gP.w = 0.0f;
-        if (ph < (float)(2 * kEpsA / 10)) gP.h = 0.0f;
-        if (tw < (float)(kEpsA / 10)) gT.w = 0.0f;
-        if (th < (float)(kEpsA / 10)) gT.h = 0.0f;
-        if (pa < (float)(-2 * pi + 2 * kEpsA) || pa > (float)(2 * pi - kEpsA)) gP.a = 0.0f;
-        if (ta < (float)(-2 * pi + kEpsA) || ta > (float)(2 * pi - 2 * kEpsA)) gT.a = 0.0f;
-    }
+    // -- gates of the rotated jitter's clamps and of the reference's acos(clamp) floors --
+    if (!f.g_wg) gP.w = 0.0f;
+    if (!f.g_hg) gP.h = 0.0f;
+    if (!f.g_wp) gT.w = 0.0f;
+    if (!f.g_hp) gT.h = 0.0f;
+    float GA = f.g_A ? 0.5f * (gT.x - gP.x) : 0.0f;  // x_p = +A/2, x_g = -A/2
+    float Gag = f.g_ag ? gP.a : 0.0f;
+    float Gap = f.g_ap ? gT.a : 0.0f;
 
     // -- chain through the transform: planar (x, w, h, a) -> spherical radians --
-    SBox g = load_sbox<DIM>(b1), p = load_sbox<DIM>(b2);
-    float cD = p.ct * g.ct + p.st * g.st;  // cos(theta_p - theta_g)
-    float sD = p.st * g.ct - p.ct * g.st;  // sin(theta_p - theta_g)
-    float N = p.sp * g.cp * cD - p.cp * g.sp;   //  c_p . d_g
-    float D = -p.sp * sD;                       // -c_p . e_g
-    float Np = g.cp * p.sp - g.sp * p.cp * cD;  // -c_g . d_p
-    float Dp = -g.sp * sD;                      //  c_g . e_p
-    float C = g.cp * p.cp + g.sp * p.sp * cD;   //  cos A
-    float sin2 = N * N + D * D;                 //  sin^2 A
+    const float sg = f.sg, cg = f.cg, sp = f.sp, cp = f.cp, sD = f.sD, cD = f.cD;
+    float N = sp * cg * cD - cp * sg;    //  c_p . d_g
+    float D = -sp * sD;                  // -c_p . e_g
+    float Np = cg * sp - sg * cp * cD;   // -c_g . d_p
+    float Dp = -sg * sD;                 //  c_g . e_p
+    float C = cg * cp + sg * sp * cD;    //  cos A
+    float sin2 = N * N + D * D;          //  sin^2 A
     float sinA = sqrtf(sin2);
-    float A = atan2f(sinA, C);
-    // gates of acos(clamp(., -1+1e-7, 1-1e-7)): compute_spherical_coordinate / compute_internal_angle
-    const float kMinAng = 4.8828125e-4f;  // acos(0.99999988)
-    float GA = (A > 2.0f * kMinAng) ? 0.5f * (gT.x - gP.x) : 0.0f;  // x_p = +A/2, x_g = -A/2
-    float Gag = (fabsf(cosf(P0.a)) < kClampHi) ? gP.a : 0.0f;
-    float Gap = (fabsf(cosf(T0.a)) < kClampHi) ? gT.a : 0.0f;
     float inv_s2 = sin2 > 1e-20f ? 1.0f / sin2 : 0.0f;
     float inv_s = sin2 > 1e-20f ? 1.0f / sinA : 0.0f;
     // dA = -dC / sinA
     float dA_phg = -N * inv_s, dA_php = Np * inv_s;
-    float dA_thg = -(g.sp * p.sp * sD) * inv_s, dA_thp = (g.sp * p.sp * sD) * inv_s;
+    float dA_thg = -(sg * sp * sD) * inv_s, dA_thp = (sg * sp * sD) * inv_s;
     // dB_g = (D dN - N dD) / sin^2 A
     float dBg_phg = (D * (-C)) * inv_s2;
-    float dBg_thg = (D * (p.sp * g.cp * sD) - N * (p.sp * cD)) * inv_s2;
-    float dpdg = p.cp * g.cp * cD + p.sp * g.sp;  // d_p . d_g
-    float dBg_php = (D * dpdg - N * (-p.cp * sD)) * inv_s2;
-    float dBg_thp = (D * (-p.sp * g.cp * sD) - N * (-p.sp * cD)) * inv_s2;
+    float dBg_thg = (D * (sp * cg * sD) - N * (sp * cD)) * inv_s2;
+    float dpdg = cp * cg * cD + sp * sg;  // d_p . d_g
+    float dBg_php = (D * dpdg - N * (-cp * sD)) * inv_s2;
+    float dBg_thp = (D * (-sp * cg * sD) - N * (-sp * cD)) * inv_s2;
     // dB_p = (D' dN' - N' dD') / sin^2 A
     float dBp_php = (Dp * C) * inv_s2;
-    float dBp_thp = (Dp * (g.sp * p.cp * sD) - Np * (-g.sp * cD)) * inv_s2;
-    float dBp_phg = (Dp * (-dpdg) - Np * (-g.cp * sD)) * inv_s2;
-    float dBp_thg = (Dp * (-g.sp * p.cp * sD) - Np * (g.sp * cD)) * inv_s2;
+    float dBp_thp = (Dp * (sg * cp * sD) - Np * (-sg * cD)) * inv_s2;
+    float dBp_phg = (Dp * (-dpdg) - Np * (-cg * sD)) * inv_s2;
+    float dBp_thg = (Dp * (-sg * cp * sD) - Np * (sg * cD)) * inv_s2;
 
     float r_g[5], r_p[5];  // gradients w.r.t. radians
     r_g[0] = GA * dA_thg + Gag * dBg_thg + Gap * dBp_thg;

@@ -20,6 +20,11 @@ from .. import _torch_glue as G
 from ..registry import LOSSES
 
 LOSS_MODES = {'iou': 0, 'giou': 1, 'diou': 2, 'ciou': 3}
+
+
+def _mode_code(mode):
+    """loss mode | arithmetic flag (reference-order transform when set_arithmetic('reference') is active)."""
+    return LOSS_MODES[mode] | (G.FLAG_REFERENCE_ORDER if G.get_arithmetic() == 'reference' else 0)
 _F32_EPS = float(torch.finfo(torch.float32).eps)
 
 
@@ -42,11 +47,11 @@ class _Sph2PobLossFunction(torch.autograd.Function):
         ctx.meta = (mode_c, eps, scale, reduce, wd, pred.dtype, target.dtype)
         if not reduce:
             return elem
-        out = torch.zeros((), dtype=torch.float32, device=dev)
-        if n:
-            ws = torch.empty((_lib.lib().sph2pob_sum_workspace_floats(),), dtype=torch.float32, device=dev)
-            G.call('sph2pob_sum_f32', dev, G.ptr(elem), ctypes.c_int64(n), ctypes.c_float(1.0), G.ptr(out), G.ptr(ws),
-                   G.stream_of(p))
+        if not n:
+            return torch.zeros((), dtype=torch.float32, device=dev)
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        G.call('sph2pob_sum_f32', dev, G.ptr(elem), ctypes.c_int64(n), ctypes.c_float(1.0),
+               ctypes.c_void_p(out.data_ptr()), G.ptr(G.sum_workspace(dev)), G.stream_of(p))
         return out
 
     @staticmethod
@@ -75,9 +80,9 @@ def sph2pob_iou_loss(pred, target, weight=None, mode='iou', eps=1e-6, reduction=
         raise ValueError('avg_factor can not be used with reduction="sum"')
     n = pred.size(0)
     if reduction == 'none':
-        return _Sph2PobLossFunction.apply(pred, target, weight, LOSS_MODES[mode], float(eps), float(loss_weight), False)
+        return _Sph2PobLossFunction.apply(pred, target, weight, _mode_code(mode), float(eps), float(loss_weight), False)
     assert reduction in ('mean', 'sum')
-    total = _Sph2PobLossFunction.apply(pred, target, weight, LOSS_MODES[mode], float(eps), float(loss_weight), True)
+    total = _Sph2PobLossFunction.apply(pred, target, weight, _mode_code(mode), float(eps), float(loss_weight), True)
     if reduction == 'sum':
         return total
     if avg_factor is None:

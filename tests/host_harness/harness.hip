@@ -8,13 +8,13 @@
 
 using namespace sph2pob;
 
-template <int DIM>
+template <int DIM, bool FAST>
 static void loss_loop(const float* pred, const float* target, int64_t n, int mode, float eps, float* loss, float* iou,
                       float* gp, float* gt) {
     for (int64_t i = 0; i < n; i++) {
         float x[5] = {0, 0, 0, 0, 0}, y[5] = {0, 0, 0, 0, 0}, gx[5], gy[5], io;
         for (int k = 0; k < DIM; k++) { x[k] = pred[i * DIM + k]; y[k] = target[i * DIM + k]; }
-        loss[i] = pair_loss<DIM, true>(x, y, mode, eps, &io, gx, gy);
+        loss[i] = pair_loss<DIM, true, FAST>(x, y, mode, eps, &io, gx, gy);
         iou[i] = io;
         for (int k = 0; k < DIM; k++) { gp[i * DIM + k] = gx[k]; gt[i * DIM + k] = gy[k]; }
     }
@@ -45,9 +45,9 @@ int harness_iou_fast(const float* b1, const float* b2, int64_t n, int dim, int v
     return 0;
 }
 int harness_loss(const float* pred, const float* target, int64_t n, int dim, int mode, float eps, float* loss,
-                 float* iou, float* gp, float* gt) {
-    if (dim == 4) loss_loop<4>(pred, target, n, mode, eps, loss, iou, gp, gt);
-    else loss_loop<5>(pred, target, n, mode, eps, loss, iou, gp, gt);
+                 float* iou, float* gp, float* gt, int fast) {
+    if (fast) { if (dim == 4) loss_loop<4, true>(pred, target, n, mode, eps, loss, iou, gp, gt); else loss_loop<5, true>(pred, target, n, mode, eps, loss, iou, gp, gt); }
+    else { if (dim == 4) loss_loop<4, false>(pred, target, n, mode, eps, loss, iou, gp, gt); else loss_loop<5, false>(pred, target, n, mode, eps, loss, iou, gp, gt); }
     return 0;
 }
 int harness_iou(const float* b1, const float* b2, int64_t n, int dim, int variant, int mode, int edge, int angle,

@@ -16,13 +16,21 @@ def L():
     return losses
 
 
+@pytest.fixture(params=['fast', 'reference'])
+def arith(request):
+    import sph_retina_amd as S
+    S.set_arithmetic(request.param)
+    yield request.param
+    S.set_arithmetic('fast')
+
+
 def cu(a, grad=False):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda().requires_grad_(grad)
 
 
 @pytest.mark.parametrize('box', ['bfov', 'rbfov'])
 @pytest.mark.parametrize('mode', ['iou', 'giou', 'diou', 'ciou'])
-def test_values_and_grads_vs_reference_fixture(L, box, mode):
+def test_values_and_grads_vs_reference_fixture(L, box, mode, arith):
     g = load_golden('loss_' + box)
     pred, target = cu(g['pred'], True), cu(g['target'], True)
     loss = L.Sph2PobIoULoss(mode=mode, reduction='none')(pred, target)
@@ -39,7 +47,7 @@ def test_values_and_grads_vs_reference_fixture(L, box, mode):
 
 
 @pytest.mark.parametrize('box', ['bfov', 'rbfov'])
-def test_reductions_weights_avg_factor(L, box):
+def test_reductions_weights_avg_factor(L, box, arith):
     g = load_golden('loss_' + box)
     pred, target = cu(g['pred']), cu(g['target'])
     w1, w2 = cu(g['w1']), cu(g['w2'])
@@ -85,7 +93,7 @@ def test_registry_build_and_target_grad_optional(L):
 
 
 @pytest.mark.parametrize('box', ['bfov', 'rbfov'])
-def test_grad_vs_fp64_finite_differences(L, oracle, box):
+def test_grad_vs_fp64_finite_differences(L, oracle, box, arith):
     g = load_golden('loss_' + box)
     sl = slice(0, 150)
     for mode in ('iou', 'ciou'):

@@ -51,12 +51,13 @@ def test_device_options_on_host(host_harness):
         assert s['mean'] < 2e-6 and s['n4'] <= 3, (key, s)
 
 
+@pytest.mark.parametrize('fast', [True, False])
 @pytest.mark.parametrize('box', ['bfov', 'rbfov'])
 @pytest.mark.parametrize('mode', ['iou', 'giou', 'diou', 'ciou'])
-def test_loss_adjoint_vs_reference_autograd(host_harness, box, mode):
+def test_loss_adjoint_vs_reference_autograd(host_harness, box, mode, fast):
     """Hand-derived backward vs the reference's torch autograd (fixtures from the unmodified reference)."""
     g = load_golden('loss_' + box)
-    loss, iou, gp, gt = host_harness.loss(g['pred'], g['target'], mode)
+    loss, iou, gp, gt = host_harness.loss(g['pred'], g['target'], mode, fast=fast)
     s = err_stats(loss, g['loss_' + mode])
     assert s['mean'] < 2e-6 and s['n4'] <= 2, s
     for mine, ref in ((gp, g['gpred_' + mode]), (gt, g['gtarget_' + mode])):
@@ -67,13 +68,14 @@ def test_loss_adjoint_vs_reference_autograd(host_harness, box, mode):
         assert d.max() < 5e-3 * scale, (d.max(), scale)
 
 
+@pytest.mark.parametrize('fast', [True, False])
 @pytest.mark.parametrize('box', ['bfov', 'rbfov'])
-def test_loss_adjoint_vs_fp64_finite_differences(host_harness, oracle, box):
+def test_loss_adjoint_vs_fp64_finite_differences(host_harness, oracle, box, fast):
     """Independent check: central finite differences of the f64 oracle (no shared code with the kernels)."""
     g = load_golden('loss_' + box)
     sl = slice(0, 150)
     for mode in ('iou', 'giou', 'ciou'):
-        _, _, gp, gt = host_harness.loss(g['pred'][sl], g['target'][sl], mode)
+        _, _, gp, gt = host_harness.loss(g['pred'][sl], g['target'][sl], mode, fast=fast)
         fp, ft = oracle.loss_grad_fd(g['pred'][sl], g['target'][sl], mode=mode)
         for mine, fd in ((gp, fp), (gt, ft)):
             d = np.abs(mine - fd)
