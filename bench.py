@@ -33,6 +33,10 @@ HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s 
 VARIANT = 'standard'
 
 
+def rank_env():
+    return int(os.environ.get('RANK', '0'))
+
+
 def make_boxes(n, seed, device):
     """tests/utils/generate_data.py:31-42 (dtype='float') with the harness ranges of tests/test_all_ious.py:141-147."""
     import torch
@@ -91,6 +95,13 @@ def main():
     import torch
     import torch.distributed as dist
     from sph_retina_amd import _lib, _torch_glue as G
+    if rank_env() == 0:
+        _lib.build()   # no-op when sph_retina_amd/lib/libsph2pob_hip.so is up to date
+    else:
+        for _ in range(600):   # other ranks wait for rank 0's build instead of racing it
+            if not _lib._stale():
+                break
+            time.sleep(0.5)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
