@@ -125,6 +125,23 @@ int64_t sph2pob_nms_workspace_bytes(int64_t k);
 int sph2pob_nms_f32(const float* boxes_sorted, const int64_t* cls_sorted, int64_t k, int box_dim, int variant,
                     float iou_threshold, void* workspace, unsigned char* keep, void* stream);
 
+/*
+ * MaxIoUAssigner epilogue on a (k, n) overlaps matrix (rows = GT, columns = boxes), SURVEY §8f-1.
+ * Replaces assign_wrt_overlaps (mmdet/core/bbox/assigners/max_iou_assigner.py:135-220) for k > 0, n > 0:
+ *   max_overlaps, argmax_overlaps       = overlaps.max(dim=0)   (:171)   first maximal index on ties
+ *   gt_max_overlaps, gt_argmax_overlaps = overlaps.max(dim=1)   (:174)
+ *   assigned_gt_inds: -1; 0 where neg_iou_lo <= max < neg_iou_hi (:178-185); argmax + 1 where max >= pos_iou_thr
+ *   (:188-189); low-quality matching (:200-207) for i ascending — the reference's python loop costs one host sync
+ *   per GT.  assigned_labels (optional) = gt_labels[gt_ind - 1] or -1 (:209-216).
+ * workspace: sph2pob_assign_workspace_bytes(k, n) bytes.
+ */
+int64_t sph2pob_assign_workspace_bytes(int64_t k, int64_t n);
+int sph2pob_assign_f32(const float* overlaps, int64_t k, int64_t n, float pos_iou_thr, float neg_iou_lo,
+                       float neg_iou_hi, float min_pos_iou, int match_low_quality, int gt_max_assign_all,
+                       const int64_t* gt_labels, float* max_overlaps, int64_t* argmax_overlaps, float* gt_max_overlaps,
+                       int64_t* gt_argmax_overlaps, int64_t* assigned_gt_inds, int64_t* assigned_labels, void* workspace,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

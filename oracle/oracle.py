@@ -229,6 +229,36 @@ def batched_nms(boxes, scores, idxs, iou_threshold=0.5, max_num=None, variant='e
     return dets, keep.astype(np.int64)
 
 
+def assign_wrt_overlaps(overlaps, gt_labels=None, pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0.0,
+                        gt_max_assign_all=True, match_low_quality=True):
+    """MaxIoUAssigner.assign_wrt_overlaps: mmdet/core/bbox/assigners/max_iou_assigner.py:135-220 (numpy).
+    -> (assigned_gt_inds, max_overlaps, argmax_overlaps, gt_max_overlaps, gt_argmax_overlaps, assigned_labels)"""
+    ov = np.asarray(overlaps, dtype=np.float32)
+    k, n = ov.shape
+    gt_inds = np.full(n, -1, dtype=np.int64)
+    max_ov, argmax_ov = ov.max(0), ov.argmax(0)           # first maximal index, like torch.max(dim)
+    gt_max, gt_argmax = ov.max(1), ov.argmax(1)
+    if isinstance(neg_iou_thr, (tuple, list)):
+        gt_inds[(max_ov >= neg_iou_thr[0]) & (max_ov < neg_iou_thr[1])] = 0
+    else:
+        gt_inds[(max_ov >= 0) & (max_ov < np.float32(neg_iou_thr))] = 0
+    pos = max_ov >= np.float32(pos_iou_thr)
+    gt_inds[pos] = argmax_ov[pos] + 1
+    if match_low_quality:
+        for i in range(k):
+            if gt_max[i] >= np.float32(min_pos_iou):
+                if gt_max_assign_all:
+                    gt_inds[ov[i] == gt_max[i]] = i + 1
+                else:
+                    gt_inds[gt_argmax[i]] = i + 1
+    labels = None
+    if gt_labels is not None:
+        labels = np.full(n, -1, dtype=np.int64)
+        p = gt_inds > 0
+        labels[p] = np.asarray(gt_labels)[gt_inds[p] - 1]
+    return gt_inds, max_ov, argmax_ov.astype(np.int64), gt_max, gt_argmax.astype(np.int64), labels
+
+
 def generate_boxes(n, seed, box='bfov', alpha=(1, 100), beta=(1, 100), gamma=(-90, 90), theta=(0, 360),
                    phi=(0, 180)):
     """Synthetic boxes of the shape of tests/utils/generate_data.py:31-42 (dtype='float'), numpy RNG."""

@@ -42,13 +42,16 @@ SIGNATURES = {
                              _int, _int, ctypes.c_float, ctypes.c_void_p],
     'sph2pob_sum_workspace_floats': [],
     'sph2pob_sum_f32': [_c_f32p, _i64, ctypes.c_float, _c_f32p, _c_f32p, ctypes.c_void_p],
+    'sph2pob_assign_workspace_bytes': [_i64, _i64],
+    'sph2pob_assign_f32': [_c_f32p, _i64, _i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _int, _int,
+                           ctypes.c_void_p] + [ctypes.c_void_p] * 7 + [ctypes.c_void_p],
     'sph2pob_nms_max_boxes': [],
     'sph2pob_nms_workspace_bytes': [_i64],
     'sph2pob_nms_f32': [_c_f32p, ctypes.c_void_p, _i64, _int, _int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
                         ctypes.c_void_p],
 }
 _RESTYPES = {'sph2pob_target_arch': ctypes.c_char_p, 'sph2pob_error_string': ctypes.c_char_p,
-             'sph2pob_nms_workspace_bytes': ctypes.c_int64}
+             'sph2pob_nms_workspace_bytes': ctypes.c_int64, 'sph2pob_assign_workspace_bytes': ctypes.c_int64}
 
 ABI_VERSION = 1
 

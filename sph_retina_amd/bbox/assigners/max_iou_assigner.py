@@ -1,0 +1,103 @@
+"""MaxIoUAssigner with a fused MI355X epilogue (the immediate consumer of the pairwise IoU kernel).
+
+`SphMaxIoUAssigner` mirrors mmdet's `MaxIoUAssigner` (mmdet/core/bbox/assigners/max_iou_assigner.py:11-220): same
+constructor arguments, `assign(bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None)` and
+`assign_wrt_overlaps(overlaps, gt_labels=None)`.  The overlaps come from the Sph2Pob pairwise kernel
+(`iou_calculator(gt_bboxes, bboxes)`, :113); everything after it — both `max` reductions, the threshold steps and the
+python `for i in range(num_gts)` low-quality loop, which costs one device->host sync per GT in the reference
+(:200-207) — is three kernel launches (`sph2pob_assign_f32`) with no host synchronisation.
+Not supported (raises): `gpu_assign_thr` CPU off-loading (there is no CPU path).
+"""
+import ctypes
+
+import torch
+
+from ... import _lib
+from ... import _torch_glue as G
+from ...registry import build_iou_calculator
+
+
+class AssignResult:
+    """Minimal stand-in for mmdet's AssignResult (mmdet/core/bbox/assigners/assign_result.py): same field names."""
+
+    def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
+        self.num_gts = num_gts
+        self.gt_inds = gt_inds
+        self.max_overlaps = max_overlaps
+        self.labels = labels
+
+    @property
+    def num_preds(self):
+        return len(self.gt_inds)
+
+
+def assign_wrt_overlaps(overlaps, gt_labels=None, pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0.0,
+                        gt_max_assign_all=True, match_low_quality=True, return_extras=False):
+    """assign_wrt_overlaps (max_iou_assigner.py:135-220) on a (k, n) overlaps matrix living on the MI355X."""
+    num_gts, num_bboxes = overlaps.size(0), overlaps.size(1)
+    if num_gts == 0 or num_bboxes == 0:  # :148-165
+        gt_inds = overlaps.new_full((num_bboxes,), -1, dtype=torch.long)
+        if num_gts == 0:
+            gt_inds[:] = 0
+        labels = None if gt_labels is None else overlaps.new_full((num_bboxes,), -1, dtype=torch.long)
+        return AssignResult(num_gts, gt_inds, overlaps.new_zeros((num_bboxes,)), labels=labels)
+    G.require_hip(overlaps)
+    ov = G.as_f32(overlaps.detach())
+    dev = ov.device
+    if isinstance(neg_iou_thr, (tuple, list)):
+        assert len(neg_iou_thr) == 2
+        neg_lo, neg_hi = float(neg_iou_thr[0]), float(neg_iou_thr[1])
+    else:
+        neg_lo, neg_hi = 0.0, float(neg_iou_thr)
+    max_ov = torch.empty((num_bboxes,), dtype=torch.float32, device=dev)
+    argmax_ov = torch.empty((num_bboxes,), dtype=torch.int64, device=dev)
+    gt_max = torch.empty((num_gts,), dtype=torch.float32, device=dev)
+    gt_argmax = torch.empty((num_gts,), dtype=torch.int64, device=dev)
+    gt_inds = torch.empty((num_bboxes,), dtype=torch.int64, device=dev)
+    labels = gl = None
+    if gt_labels is not None:
+        gl = gt_labels.to(device=dev, dtype=torch.int64).contiguous()
+        labels = torch.empty((num_bboxes,), dtype=torch.int64, device=dev)
+    ws = torch.empty((_lib.lib().sph2pob_assign_workspace_bytes(num_gts, num_bboxes) // 8,), dtype=torch.int64, device=dev)
+    G.call('sph2pob_assign_f32', dev, G.ptr(ov), ctypes.c_int64(num_gts), ctypes.c_int64(num_bboxes),
+           ctypes.c_float(pos_iou_thr), ctypes.c_float(neg_lo), ctypes.c_float(neg_hi), ctypes.c_float(min_pos_iou),
+           int(bool(match_low_quality)), int(bool(gt_max_assign_all)), G.ptr(gl), G.ptr(max_ov), G.ptr(argmax_ov),
+           G.ptr(gt_max), G.ptr(gt_argmax), G.ptr(gt_inds), G.ptr(labels), G.ptr(ws), G.stream_of(ov))
+    res = AssignResult(num_gts, gt_inds, max_ov if overlaps.dtype == torch.float32 else max_ov.to(overlaps.dtype), labels)
+    if return_extras:
+        return res, dict(argmax_overlaps=argmax_ov, gt_max_overlaps=gt_max, gt_argmax_overlaps=gt_argmax)
+    return res
+
+
+class SphMaxIoUAssigner:
+    """Same constructor as mmdet's MaxIoUAssigner (:45-65); `iou_calculator` defaults to the Sph2Pob standard IoU."""
+
+    def __init__(self, pos_iou_thr, neg_iou_thr, min_pos_iou=.0, gt_max_assign_all=True, ignore_iof_thr=-1,
+                 ignore_wrt_candidates=True, match_low_quality=True, gpu_assign_thr=-1,
+                 iou_calculator=dict(type='SphOverlaps2D', backend='sph2pob_standard_iou', box_version=4)):
+        self.pos_iou_thr = pos_iou_thr
+        self.neg_iou_thr = neg_iou_thr
+        self.min_pos_iou = min_pos_iou
+        self.gt_max_assign_all = gt_max_assign_all
+        self.ignore_iof_thr = ignore_iof_thr
+        self.ignore_wrt_candidates = ignore_wrt_candidates
+        self.gpu_assign_thr = gpu_assign_thr
+        self.match_low_quality = match_low_quality
+        self.iou_calculator = build_iou_calculator(iou_calculator) if isinstance(iou_calculator, dict) else iou_calculator
+
+    def assign(self, bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None):
+        if self.gpu_assign_thr > 0 and gt_bboxes.shape[0] > self.gpu_assign_thr:
+            raise NotImplementedError('gpu_assign_thr (CPU off-loading) is not available: the engine has no CPU path')
+        overlaps = self.iou_calculator(gt_bboxes, bboxes)  # rows = GT (:113)
+        if (self.ignore_iof_thr > 0 and gt_bboxes_ignore is not None and gt_bboxes_ignore.numel() > 0
+                and bboxes.numel() > 0):  # :115-126
+            if self.ignore_wrt_candidates:
+                ignore_max, _ = self.iou_calculator(bboxes, gt_bboxes_ignore, mode='iof').max(dim=1)
+            else:
+                ignore_max, _ = self.iou_calculator(gt_bboxes_ignore, bboxes, mode='iof').max(dim=0)
+            overlaps[:, ignore_max > self.ignore_iof_thr] = -1
+        return self.assign_wrt_overlaps(overlaps, gt_labels)
+
+    def assign_wrt_overlaps(self, overlaps, gt_labels=None):
+        return assign_wrt_overlaps(overlaps, gt_labels, self.pos_iou_thr, self.neg_iou_thr, self.min_pos_iou,
+                                   self.gt_max_assign_all, self.match_low_quality)

@@ -444,6 +444,96 @@ __global__ __launch_bounds__(kBlock) void nms_sweep_kernel(const unsigned long l
     }
 }
 
+// ---- MaxIoUAssigner epilogue: replaces overlaps.max(dim=0), overlaps.max(dim=1), the threshold steps
+// and the python `for i in range(num_gts)` low-quality loop (one host sync per GT) of
+// mmdet/core/bbox/assigners/max_iou_assigner.py:171-207 with three launches over the (k, n) overlaps matrix. ----
+__device__ __forceinline__ unsigned long long pack_max_key(float v, int64_t j) {
+    // IoUs are >= 0 (or -1 for ignored columns): map to an order-preserving unsigned key; ties -> smallest index
+    unsigned u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned)(0xffffffffu - (unsigned)j);
+}
+__device__ __forceinline__ float unpack_max_val(unsigned long long key) {
+    unsigned u = (unsigned)(key >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long w = __shfl_xor(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+// A: one thread per column (anchor): running max / first argmax over the k rows, and per-wave row partials
+__global__ __launch_bounds__(kBlock) void assign_cols_kernel(const float* __restrict__ ov, int k, int64_t n,
+                                                            float* __restrict__ max_ov, int64_t* __restrict__ argmax_ov,
+                                                            unsigned long long* __restrict__ partial, int nparts) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int part = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const bool valid = j < n;
+    float best = -__builtin_inff();
+    int besti = 0;
+    for (int i = 0; i < k; i++) {
+        float v = valid ? ov[(int64_t)i * n + j] : -__builtin_inff();
+        if (v > best) { best = v; besti = i; }
+        unsigned long long key = wave_max_u64(valid ? pack_max_key(v, j) : 0ull);
+        if (lane == 0) partial[(int64_t)i * nparts + part] = key;
+    }
+    if (valid) { max_ov[j] = best; argmax_ov[j] = besti; }
+}
+// B: one workgroup per row (GT): reduce the per-wave partials
+__global__ __launch_bounds__(kBlock) void assign_rows_kernel(const unsigned long long* __restrict__ partial, int nparts,
+                                                            float* __restrict__ gt_max, int64_t* __restrict__ gt_argmax) {
+    __shared__ unsigned long long sm[kBlock / 64];
+    const int i = blockIdx.x;
+    unsigned long long best = 0ull;
+    for (int p = threadIdx.x; p < nparts; p += kBlock) {
+        unsigned long long v = partial[(int64_t)i * nparts + p];
+        best = v > best ? v : best;
+    }
+    best = wave_max_u64(best);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; w++) best = sm[w] > best ? sm[w] : best;
+        gt_max[i] = unpack_max_val(best);
+        gt_argmax[i] = (int64_t)(0xffffffffu - (unsigned)best);
+    }
+}
+// C: thresholds + low-quality matching, one thread per column; later GTs overwrite earlier ones like the python loop
+__global__ __launch_bounds__(kBlock) void assign_finalize_kernel(const float* __restrict__ ov, int k, int64_t n,
+                                                                const float* __restrict__ max_ov,
+                                                                const int64_t* __restrict__ argmax_ov,
+                                                                const float* __restrict__ gt_max,
+                                                                const int64_t* __restrict__ gt_argmax, float pos_thr,
+                                                                float neg_lo, float neg_hi, float min_pos,
+                                                                int low_quality, int assign_all,
+                                                                const int64_t* __restrict__ gt_labels,
+                                                                int64_t* __restrict__ gt_inds,
+                                                                int64_t* __restrict__ labels) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    const float m = max_ov[j];
+    int64_t a = -1;
+    if (m >= neg_lo && m < neg_hi) a = 0;
+    if (m >= pos_thr) a = argmax_ov[j] + 1;
+    if (low_quality) {
+        for (int i = 0; i < k; i++) {
+            const float g = gt_max[i];
+            if (g >= min_pos) {
+                if (assign_all ? (ov[(int64_t)i * n + j] == g) : (gt_argmax[i] == j)) a = i + 1;
+            }
+        }
+    }
+    gt_inds[j] = a;
+    if (labels) labels[j] = a > 0 ? gt_labels[a - 1] : -1;
+}
+
 int check_common(int box_dim, int variant_flags, int edge, int angle) {
     const int variant = variant_flags & 0xff;
     if (variant_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER)) return SPH2POB_ERR_OPTION;
@@ -677,6 +767,34 @@ int sph2pob_nms_f32(const float* boxes_sorted, const int64_t* cls_sorted, int64_
     int rc = launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(nms_sweep_kernel, dim3((unsigned)((k + wpb - 1) / wpb)), dim3(kBlock), 0, s, mask, cls_sorted, k, words, keep);
+    return launch_status();
+}
+
+int64_t sph2pob_assign_workspace_bytes(int64_t k, int64_t n) {
+    int64_t nparts = ((n + kBlock - 1) / kBlock) * (kBlock / 64);
+    return k * nparts * 8;
+}
+
+int sph2pob_assign_f32(const float* overlaps, int64_t k, int64_t n, float pos_iou_thr, float neg_iou_lo,
+                       float neg_iou_hi, float min_pos_iou, int match_low_quality, int gt_max_assign_all,
+                       const int64_t* gt_labels, float* max_overlaps, int64_t* argmax_overlaps, float* gt_max_overlaps,
+                       int64_t* gt_argmax_overlaps, int64_t* assigned_gt_inds, int64_t* assigned_labels, void* workspace,
+                       void* stream) {
+    if (k <= 0 || n <= 0 || k > 0x7fffffff || n > kMaxElems || n > (int64_t)0xfffffffe) return SPH2POB_ERR_SIZE;
+    if (!overlaps || !max_overlaps || !argmax_overlaps || !gt_max_overlaps || !gt_argmax_overlaps || !assigned_gt_inds ||
+        !workspace || (assigned_labels && !gt_labels))
+        return SPH2POB_ERR_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((n + kBlock - 1) / kBlock);
+    const int nparts = (int)(blocks * (kBlock / 64));
+    unsigned long long* partial = (unsigned long long*)workspace;
+    hipLaunchKernelGGL(assign_cols_kernel, dim3(blocks), dim3(kBlock), 0, s, overlaps, (int)k, n, max_overlaps,
+                       argmax_overlaps, partial, nparts);
+    hipLaunchKernelGGL(assign_rows_kernel, dim3((unsigned)k), dim3(kBlock), 0, s, partial, nparts, gt_max_overlaps,
+                       gt_argmax_overlaps);
+    hipLaunchKernelGGL(assign_finalize_kernel, dim3(blocks), dim3(kBlock), 0, s, overlaps, (int)k, n, max_overlaps,
+                       argmax_overlaps, gt_max_overlaps, gt_argmax_overlaps, pos_iou_thr, neg_iou_lo, neg_iou_hi,
+                       min_pos_iou, match_low_quality, gt_max_assign_all, gt_labels, assigned_gt_inds, assigned_labels);
     return launch_status();
 }
 

@@ -1,0 +1,84 @@
+"""GPU: fused MaxIoUAssigner epilogue (sph2pob_assign_f32) vs the numpy restatement of mmdet's assign_wrt_overlaps,
+mmdet's own known-answer cases, and the config-4 call pattern end to end."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def A():
+    import sph_retina_amd.bbox.assigners as assigners
+    assert torch.cuda.is_available()
+    return assigners
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def check(A, oracle, ov, labels=None, **kw):
+    res, ex = A.assign_wrt_overlaps(cu(ov), None if labels is None else cu(labels), return_extras=True, **kw)
+    gi, mo, amo, gm, gam, lab = oracle.assign_wrt_overlaps(ov, labels, **kw)
+    np.testing.assert_array_equal(res.gt_inds.cpu().numpy(), gi)
+    np.testing.assert_array_equal(res.max_overlaps.cpu().numpy(), mo)
+    np.testing.assert_array_equal(ex['argmax_overlaps'].cpu().numpy(), amo)
+    np.testing.assert_array_equal(ex['gt_max_overlaps'].cpu().numpy(), gm)
+    np.testing.assert_array_equal(ex['gt_argmax_overlaps'].cpu().numpy(), gam)
+    if labels is not None:
+        np.testing.assert_array_equal(res.labels.cpu().numpy(), lab)
+    return res
+
+
+@pytest.mark.parametrize('k,n', [(1, 1), (3, 70), (64, 1000), (17, 4099), (200, 333)])
+def test_random_matrices_bit_exact(A, oracle, k, n):
+    rng = np.random.default_rng(k * 1000 + n)
+    ov = rng.random((k, n)).astype(np.float32)
+    ov[ov < 0.7] = 0.0                                   # sparse like real anchor/GT overlaps, many exact ties at 0
+    ov[:, rng.integers(0, n, max(1, n // 10))] = -1.0     # ignored columns (max_iou_assigner.py:126)
+    if n > 5:
+        ov[0, 3] = ov[0, 5] = ov[0].max()                 # ties on a row maximum -> gt_max_assign_all hits both
+    labels = rng.integers(0, 37, k)
+    for kw in (dict(pos_iou_thr=0.8, neg_iou_thr=0.75, min_pos_iou=0.0),
+               dict(pos_iou_thr=0.9, neg_iou_thr=(0.1, 0.8), min_pos_iou=0.75, gt_max_assign_all=False),
+               dict(pos_iou_thr=0.8, neg_iou_thr=0.8, match_low_quality=False)):
+        check(A, oracle, ov, labels, **kw)
+        check(A, oracle, ov, None, **kw)
+
+
+def test_mmdet_known_answers(A):
+    """tests/test_utils/test_assigner.py:19-40 of the vendored mmdet: planar IoUs of its 4 boxes vs 2 GTs."""
+    ov = np.array([[0.81, 0.0476, 0.0, 0.0], [0.0, 0.6328, 0.0, 0.0]], np.float32)  # IoU(gt, boxes), same ordering
+    res = A.assign_wrt_overlaps(cu(ov), cu(np.array([2, 3])), pos_iou_thr=0.5, neg_iou_thr=0.5)
+    assert res.gt_inds.tolist() == [1, 2, 0, 0]        # expected_gt_inds at test_assigner.py:38
+    assert res.labels.tolist() == [2, 3, -1, -1]
+    empty = A.assign_wrt_overlaps(torch.zeros((0, 4), device='cuda'), None, pos_iou_thr=0.5, neg_iou_thr=0.5)
+    assert empty.gt_inds.tolist() == [0, 0, 0, 0] and empty.num_gts == 0
+    none = A.assign_wrt_overlaps(torch.zeros((2, 0), device='cuda'), cu(np.array([1, 2])), pos_iou_thr=0.5, neg_iou_thr=0.5)
+    assert none.gt_inds.numel() == 0 and none.labels.numel() == 0
+
+
+def test_config4_call_pattern_end_to_end(A, oracle):
+    """RetinaNet assigner of the reference config (pos 0.5 / neg 0.4 / min_pos 0): 64 GT x ~98k anchors."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from bench_configs import retina_anchors
+    anchors = retina_anchors()
+    g = torch.Generator().manual_seed(0)
+    u = torch.rand((64, 4), generator=g)
+    gt = torch.stack([u[:, 0] * 360, 20 + u[:, 1] * 140, 5 + u[:, 2] * 85, 5 + u[:, 3] * 85], 1).cuda()
+    labels = torch.randint(0, 37, (64,), generator=g).cuda()
+    assigner = A.SphMaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0, ignore_iof_thr=-1)
+    res = assigner.assign(anchors, gt, gt_labels=labels)
+    assert res.gt_inds.shape == (anchors.size(0),) and res.num_gts == 64
+    ov = assigner.iou_calculator(gt, anchors).cpu().numpy()
+    gi, mo, *_rest, lab = oracle.assign_wrt_overlaps(ov, labels.cpu().numpy(), pos_iou_thr=0.5, neg_iou_thr=0.4)
+    np.testing.assert_array_equal(res.gt_inds.cpu().numpy(), gi)
+    np.testing.assert_array_equal(res.max_overlaps.cpu().numpy(), mo)
+    np.testing.assert_array_equal(res.labels.cpu().numpy(), lab)
+    assert (gi > 0).sum() >= 64  # every GT got at least its best anchor (low-quality matching)
+    # and the overlaps themselves against the CPU oracle on a column sample
+    cols = np.arange(0, anchors.size(0), 97)
+    want = oracle.iou_pairwise(gt.cpu().numpy(), anchors.cpu().numpy()[cols], variant='standard')
+    assert np.abs(ov[:, cols] - want).mean() < 1e-6
