@@ -80,6 +80,17 @@ int sph2pob_transform_f32(const float* b1, const float* b2, float* planar1, floa
                           int box_dim, int variant, int edge, int angle, int jitter, void* stream);
 
 /*
+ * Adjoint of sph2pob_transform_f32 for variant STANDARD | EFFICIENT, rbb_angle 'equator': given the gradients of a
+ * scalar w.r.t. the two (n, 5) planar boxes, writes its gradients w.r.t. the two (n, box_dim) spherical boxes
+ * (degrees).  This is what lets every Sph2Pob-wrapped OBB loss (Sph2PobTransfrom.new_forward,
+ * sphdet/losses/sph2pob_transform.py:24-35: L1 / GD / KF / IoU bodies) back-propagate to the spherical inputs without
+ * torch autograd through the ~70 transform ops.  With jitter != 0 the clamp gates of both jitters are applied.
+ */
+int sph2pob_transform_bwd_f32(const float* b1, const float* b2, const float* grad_planar1, const float* grad_planar2,
+                              float* grad_b1, float* grad_b2, int64_t n, int box_dim, int variant, int edge, int jitter,
+                              void* stream);
+
+/*
  * Sph2PobIoULoss element values: loss[i] = scale * w_i * L(pred[i], target[i]), L = 1 - IoU | GIoU | DIoU | CIoU
  * form; scale carries loss_weight (sph2pob_iou_loss.py:49).
  * Replaces Sph2PobTransfrom.new_forward (sphdet/losses/sph2pob_transform.py:24-35: clone, spherical jitter,

@@ -196,6 +196,32 @@ def loss_grad_fd(pred, target, mode='iou', eps=1e-6, h=1e-5):
     return gp, gt
 
 
+def transform_vjp_fd(b1, b2, g1, g2, variant='standard', edge='arc', jitter=True, h=1e-5):
+    """f64 central finite differences of  sum(g1 * planar1 + g2 * planar2)  w.r.t. the spherical inputs (degrees):
+    the vector-Jacobian product the HIP transform adjoint must reproduce."""
+    b1 = _np(b1, np.float64)
+    b2 = _np(b2, np.float64)
+    g1 = _np(g1, np.float64)
+    g2 = _np(g2, np.float64)
+
+    def f():
+        p1, p2 = transform(b1, b2, variant=variant, edge=edge, jitter=jitter, dtype=np.float64)
+        return (g1 * p1).sum(1) + (g2 * p2).sum(1)
+    out = []
+    for arr in (b1, b2):
+        g = np.zeros_like(arr)
+        for k in range(arr.shape[1]):
+            save = arr[:, k].copy()
+            arr[:, k] = save + h
+            fp = f()
+            arr[:, k] = save - h
+            fm = f()
+            arr[:, k] = save
+            g[:, k] = (fp - fm) / (2 * h)
+        out.append(g)
+    return out
+
+
 def nms_op(boxes, scores, iou_threshold, variant='efficient', planar='mmcv'):
     """sph_nms_op: sphdet/bbox/nms/sph_nms.py:62-74.  Stable descending sort (ties keep input order)."""
     boxes = _np(boxes, np.float32)

@@ -123,17 +123,96 @@ SPH_DEV void loss_front_reference(const float (&b1)[5], const float (&b2)[5], Lo
 namespace sph2pob {
 
 // closed-form front end (sph2pob_fast.hpp): same planar boxes, ~4x fewer instructions
-template <int DIM>
-SPH_DEV void loss_front_fast(const float (&b1)[5], const float (&b2)[5], LossFront& f) {
+template <int DIM, int VARIANT = VARIANT_STANDARD>
+SPH_DEV void loss_front_fast(const float (&b1)[5], const float (&b2)[5], LossFront& f, int edge = EDGE_ARC,
+                             bool rot_jitter = true) {
     FastRec r;
     FastTrig t;
-    fast_phase1<VARIANT_STANDARD, DIM>(b1, b2, EDGE_ARC, r, &t);
+    fast_phase1<VARIANT, DIM>(b1, b2, edge, r, &t);
     PlanarPair q;
-    fast_planar<VARIANT_STANDARD, DIM>(r, q);
+    fast_planar<VARIANT, DIM>(r, q);
+    if (!rot_jitter) { q.g_wg = q.g_hg = q.g_wp = q.g_hp = true; }
     f.dx = q.dx; f.dy = q.dy; f.ca = q.ca; f.sa = q.sa; f.cb = q.cb; f.sb = q.sb;
     f.wg = q.wg; f.hg = q.hg; f.wp = q.wp; f.hp = q.hp;
     f.g_A = q.g_A; f.g_ag = q.g_ag; f.g_ap = q.g_ap; f.g_wg = q.g_wg; f.g_hg = q.g_hg; f.g_wp = q.g_wp; f.g_hp = q.g_hp;
     f.sg = t.sg; f.cg = t.cg; f.sp = t.sp; f.cp = t.cp; f.sD = t.sD; f.cD = t.cD;
+}
+
+// Chain rule from gradients w.r.t. the two planar boxes (x, w, h, a) to gradients w.r.t. the spherical inputs
+// (degrees).  x_split: P.x = -x_split*A and T.x = +(1 - x_split)*A ... expressed as dT.x/dA - dP.x/dA = 1:
+// standard (x = -+A/2) passes 0.5, efficient (P.x = 0, T.x = A) passes 0.  Gates: acos(clamp) floors and the rotated
+// jitter's clamps (from the front end), the spherical jitter's in-place clamps (here, when `jitter`).
+template <int DIM>
+SPH_DEV void planar_to_spherical_grads(const LossFront& f, PlanarGrad gP, PlanarGrad gT, float x_split,
+                                       const float (&pred)[5], const float (&target)[5], bool jitter, int edge,
+                                       float (&gpred)[5], float (&gtarget)[5]) {
+    if (!f.g_wg) gP.w = 0.0f;
+    if (!f.g_hg) gP.h = 0.0f;
+    if (!f.g_wp) gT.w = 0.0f;
+    if (!f.g_hp) gT.h = 0.0f;
+    float GA = f.g_A ? ((1.0f - x_split) * gT.x - x_split * gP.x) : 0.0f;
+    float Gag = f.g_ag ? gP.a : 0.0f;
+    float Gap = f.g_ap ? gT.a : 0.0f;
+    const float sg = f.sg, cg = f.cg, sp = f.sp, cp = f.cp, sD = f.sD, cD = f.cD;
+    float N = sp * cg * cD - cp * sg;    //  c_p . d_g
+    float D = -sp * sD;                  // -c_p . e_g
+    float Np = cg * sp - sg * cp * cD;   // -c_g . d_p
+    float Dp = -sg * sD;                 //  c_g . e_p
+    float C = cg * cp + sg * sp * cD;    //  cos A
+    float sin2 = N * N + D * D;          //  sin^2 A
+    float sinA = sqrtf(sin2);
+    float inv_s2 = sin2 > 1e-20f ? 1.0f / sin2 : 0.0f;
+    float inv_s = sin2 > 1e-20f ? 1.0f / sinA : 0.0f;
+    // dA = -dC / sinA
+    float dA_phg = -N * inv_s, dA_php = Np * inv_s;
+    float dA_thg = -(sg * sp * sD) * inv_s, dA_thp = (sg * sp * sD) * inv_s;
+    // dB_g = (D dN - N dD) / sin^2 A
+    float dBg_phg = (D * (-C)) * inv_s2;
+    float dBg_thg = (D * (sp * cg * sD) - N * (sp * cD)) * inv_s2;
+    float dpdg = cp * cg * cD + sp * sg;  // d_p . d_g
+    float dBg_php = (D * dpdg - N * (-cp * sD)) * inv_s2;
+    float dBg_thp = (D * (-sp * cg * sD) - N * (-sp * cD)) * inv_s2;
+    // dB_p = (D' dN' - N' dD') / sin^2 A
+    float dBp_php = (Dp * C) * inv_s2;
+    float dBp_thp = (Dp * (sg * cp * sD) - Np * (-sg * cD)) * inv_s2;
+    float dBp_phg = (Dp * (-dpdg) - Np * (-cg * sD)) * inv_s2;
+    float dBp_thg = (Dp * (-sg * cp * sD) - Np * (sg * cD)) * inv_s2;
+
+    float r_g[5], r_p[5];  // gradients w.r.t. radians
+    r_g[0] = GA * dA_thg + Gag * dBg_thg + Gap * dBp_thg;
+    r_g[1] = GA * dA_phg + Gag * dBg_phg + Gap * dBp_phg;
+    r_g[2] = gP.w; r_g[3] = gP.h; r_g[4] = -Gag;
+    r_p[0] = GA * dA_thp + Gag * dBg_thp + Gap * dBp_thp;
+    r_p[1] = GA * dA_php + Gag * dBg_php + Gap * dBp_php;
+    r_p[2] = gT.w; r_p[3] = gT.h; r_p[4] = -Gap;
+
+    // spherical-jitter shifts / clamps (sph_iou_api.py:244-258): gates look at the pre-clamp values
+    const float eps1 = (float)kEpsS, eps2 = (float)(2 * kEpsS);
+    bool similar = false;
+    if (jitter) {
+#pragma unroll
+        for (int k = 0; k < DIM; k++) similar |= fabsf(pred[k] - target[k]) < eps1;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        if (k >= DIM) { gpred[k] = 0.0f; gtarget[k] = 0.0f; continue; }
+        float x1 = pred[k] - (similar ? eps2 : 0.0f), x2 = target[k] + (similar ? eps1 : 0.0f);
+        float hi1 = k == 0 ? (float)(360.0 - kEpsS) : (float)(180.0 - kEpsS);
+        float hi2 = k == 0 ? (float)(360.0 - 2 * kEpsS) : (float)(180.0 - 2 * kEpsS);
+        bool in1 = !jitter || k == 4 || (x1 >= eps2 && x1 <= hi1);
+        bool in2 = !jitter || (k == 4 ? (x2 >= (float)(-360.0 + 2 * kEpsS) && x2 <= (float)(360.0 - 2 * kEpsS))
+                                      : (x2 >= eps1 && x2 <= hi2));
+        float s1 = kDeg2Rad, s2 = kDeg2Rad;
+        if ((k == 2 || k == 3) && edge != EDGE_ARC) {  // d(edge length)/d(fov): chord cos(f/2), tangent 1/cos^2(f/2)
+            float jg = in1 ? fminf(fmaxf(x1, jitter ? eps2 : x1), jitter ? hi1 : x1) : x1;
+            float jp = in2 ? fminf(fmaxf(x2, jitter ? eps1 : x2), jitter ? hi2 : x2) : x2;
+            float c1 = cosf(0.5f * jg * kDeg2Rad), c2 = cosf(0.5f * jp * kDeg2Rad);
+            s1 *= edge == EDGE_CHORD ? c1 : 1.0f / (c1 * c1);
+            s2 *= edge == EDGE_CHORD ? c2 : 1.0f / (c2 * c2);
+        }
+        gpred[k] = in1 ? r_g[k] * s1 : 0.0f;
+        gtarget[k] = in2 ? r_p[k] * s2 : 0.0f;
+    }
 }
 
 // Per-pair loss element; when BWD, also d(loss)/d(pred[0..DIM)) and d(loss)/d(target[0..DIM)) in 1/degree.
@@ -272,69 +351,24 @@ SPH_DEV float pair_loss(const float (&pred)[5], const float (&target)[5], int lo
         gT.w += LWp * acb + LHp * asb; gT.h += LWp * asb + LHp * acb; gT.a += LWp * dWp_a + LHp * dHp_a;
     }
 
-    // -- gates of the rotated jitter's clamps and of the reference's acos(clamp) floors --
-    if (!f.g_wg) gP.w = 0.0f;
-    if (!f.g_hg) gP.h = 0.0f;
-    if (!f.g_wp) gT.w = 0.0f;
-    if (!f.g_hp) gT.h = 0.0f;
-    float GA = f.g_A ? 0.5f * (gT.x - gP.x) : 0.0f;  // x_p = +A/2, x_g = -A/2
-    float Gag = f.g_ag ? gP.a : 0.0f;
-    float Gap = f.g_ap ? gT.a : 0.0f;
-
-    // -- chain through the transform: planar (x, w, h, a) -> spherical radians --
-    const float sg = f.sg, cg = f.cg, sp = f.sp, cp = f.cp, sD = f.sD, cD = f.cD;
-    float N = sp * cg * cD - cp * sg;    //  c_p . d_g
-    float D = -sp * sD;                  // -c_p . e_g
-    float Np = cg * sp - sg * cp * cD;   // -c_g . d_p
-    float Dp = -sg * sD;                 //  c_g . e_p
-    float C = cg * cp + sg * sp * cD;    //  cos A
-    float sin2 = N * N + D * D;          //  sin^2 A
-    float sinA = sqrtf(sin2);
-    float inv_s2 = sin2 > 1e-20f ? 1.0f / sin2 : 0.0f;
-    float inv_s = sin2 > 1e-20f ? 1.0f / sinA : 0.0f;
-    // dA = -dC / sinA
-    float dA_phg = -N * inv_s, dA_php = Np * inv_s;
-    float dA_thg = -(sg * sp * sD) * inv_s, dA_thp = (sg * sp * sD) * inv_s;
-    // dB_g = (D dN - N dD) / sin^2 A
-    float dBg_phg = (D * (-C)) * inv_s2;
-    float dBg_thg = (D * (sp * cg * sD) - N * (sp * cD)) * inv_s2;
-    float dpdg = cp * cg * cD + sp * sg;  // d_p . d_g
-    float dBg_php = (D * dpdg - N * (-cp * sD)) * inv_s2;
-    float dBg_thp = (D * (-sp * cg * sD) - N * (-sp * cD)) * inv_s2;
-    // dB_p = (D' dN' - N' dD') / sin^2 A
-    float dBp_php = (Dp * C) * inv_s2;
-    float dBp_thp = (Dp * (sg * cp * sD) - Np * (-sg * cD)) * inv_s2;
-    float dBp_phg = (Dp * (-dpdg) - Np * (-cg * sD)) * inv_s2;
-    float dBp_thg = (Dp * (-sg * cp * sD) - Np * (sg * cD)) * inv_s2;
-
-    float r_g[5], r_p[5];  // gradients w.r.t. radians
-    r_g[0] = GA * dA_thg + Gag * dBg_thg + Gap * dBp_thg;
-    r_g[1] = GA * dA_phg + Gag * dBg_phg + Gap * dBp_phg;
-    r_g[2] = gP.w; r_g[3] = gP.h; r_g[4] = -Gag;
-    r_p[0] = GA * dA_thp + Gag * dBg_thp + Gap * dBp_thp;
-    r_p[1] = GA * dA_php + Gag * dBg_php + Gap * dBp_php;
-    r_p[2] = gT.w; r_p[3] = gT.h; r_p[4] = -Gap;
-
-    // -- spherical-jitter clamp gates (sph_iou_api.py:251-258) on the pre-clamp values, then deg2rad --
-    {
-        const float eps1 = (float)kEpsS, eps2 = (float)(2 * kEpsS);
-        bool similar = false;
-#pragma unroll
-        for (int k = 0; k < DIM; k++) similar |= fabsf(pred[k] - target[k]) < eps1;
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            if (k >= DIM) { gpred[k] = 0.0f; gtarget[k] = 0.0f; continue; }
-            float x1 = pred[k] - (similar ? eps2 : 0.0f), x2 = target[k] + (similar ? eps1 : 0.0f);
-            float hi1 = k == 0 ? (float)(360.0 - kEpsS) : (float)(180.0 - kEpsS);
-            float hi2 = k == 0 ? (float)(360.0 - 2 * kEpsS) : (float)(180.0 - 2 * kEpsS);
-            bool in1 = k == 4 ? true : (x1 >= eps2 && x1 <= hi1);
-            bool in2 = k == 4 ? (x2 >= (float)(-360.0 + 2 * kEpsS) && x2 <= (float)(360.0 - 2 * kEpsS))
-                              : (x2 >= eps1 && x2 <= hi2);
-            gpred[k] = in1 ? r_g[k] * kDeg2Rad : 0.0f;
-            gtarget[k] = in2 ? r_p[k] * kDeg2Rad : 0.0f;
-        }
-    }
+    // -- chain rule back to the spherical inputs (degrees) --
+    planar_to_spherical_grads<DIM>(f, gP, gT, /*x_split=*/0.5f, pred, target, /*jitter=*/true, EDGE_ARC, gpred, gtarget);
     return loss;
+}
+
+// Adjoint of sph2pob_{standard,efficient}(...,'rad') (+ the two jitters when `jitter`): gradients of the two planar
+// boxes (x, y, w, h, a) -> gradients of the spherical inputs.  y carries no gradient (it is the constant pi/2 | 0).
+template <int VARIANT, int DIM>
+SPH_DEV void pair_transform_bwd(const float (&in1)[5], const float (&in2)[5], const float (&g1)[5], const float (&g2)[5],
+                                int edge, bool jitter, float (&gin1)[5], float (&gin2)[5]) {
+    float b1[5], b2[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) { b1[k] = in1[k]; b2[k] = in2[k]; }
+    if (jitter) jitter_spherical<DIM>(b1, b2);
+    LossFront f;
+    loss_front_fast<DIM, VARIANT>(b1, b2, f, edge, jitter);
+    PlanarGrad gP{g1[0], g1[2], g1[3], g1[4]}, gT{g2[0], g2[2], g2[3], g2[4]};
+    planar_to_spherical_grads<DIM>(f, gP, gT, VARIANT == VARIANT_STANDARD ? 0.5f : 0.0f, in1, in2, jitter, edge, gin1, gin2);
 }
 
 }  // namespace sph2pob

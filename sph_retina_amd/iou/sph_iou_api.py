@@ -72,6 +72,40 @@ def sph2pob_efficient_iou(bboxes1, bboxes2, mode='iou', is_aligned=False, calcul
 # ---------------------------------------------------------------------------------------------------------
 # Transforms: sph2pob_{standard,efficient,legacy}(sph_gt, sph_pred, rbb_angle_version='deg', ...)
 # (sphdet/iou/sph2pob_standard.py:8, sph2pob_efficient.py:9, sph2pob_legacy.py:8) -> two (n, 5) planar boxes.
+class _Sph2PobTransformFunction(torch.autograd.Function):
+    """(sph_gt, sph_pred) -> planar boxes (n, 5) x 2 in radians; backward = `sph2pob_transform_bwd_f32`."""
+
+    @staticmethod
+    def forward(ctx, sph_gt, sph_pred, variant, rbb_edge, rbb_angle, jitter):
+        n, dim = sph_gt.shape
+        b1, b2 = G.as_f32(sph_gt.detach()), G.as_f32(sph_pred.detach())
+        o1 = torch.empty((n, 5), dtype=torch.float32, device=b1.device)
+        o2 = torch.empty((n, 5), dtype=torch.float32, device=b1.device)
+        if n:
+            G.call('sph2pob_transform_f32', b1.device, G.ptr(b1), G.ptr(b2), G.ptr(o1), G.ptr(o2), ctypes.c_int64(n),
+                   dim, G.VARIANTS[variant], G.EDGES[rbb_edge], G.ANGLES.get(rbb_angle, 0), int(bool(jitter)),
+                   G.stream_of(b1))
+        ctx.save_for_backward(b1, b2)
+        ctx.meta = (variant, rbb_edge, rbb_angle, jitter, sph_gt.dtype, sph_pred.dtype)
+        return o1, o2
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        b1, b2 = ctx.saved_tensors
+        variant, rbb_edge, rbb_angle, jitter, dt1, dt2 = ctx.meta
+        if variant == 'legacy' or rbb_angle == 'project':
+            raise NotImplementedError("backward of the Sph2Pob transform is implemented for sph2pob_standard / "
+                                      "sph2pob_efficient with rbb_angle='equator'")
+        n, dim = b1.shape
+        gb1, gb2 = torch.empty_like(b1), torch.empty_like(b2)
+        if n:
+            g1, g2 = G.as_f32(g1), G.as_f32(g2)
+            G.call('sph2pob_transform_bwd_f32', b1.device, G.ptr(b1), G.ptr(b2), G.ptr(g1), G.ptr(g2), G.ptr(gb1),
+                   G.ptr(gb2), ctypes.c_int64(n), dim, G.VARIANTS[variant], G.EDGES[rbb_edge], int(bool(jitter)),
+                   G.stream_of(b1))
+        return gb1.to(dt1), gb2.to(dt2), None, None, None, None
+
+
 def _transform(variant, sph_gt, sph_pred, rbb_angle_version, rbb_edge, rbb_angle, jitter=False):
     assert rbb_angle_version in ['deg', 'rad']
     assert rbb_edge in ['arc', 'chord', 'tangent']
@@ -81,16 +115,10 @@ def _transform(variant, sph_gt, sph_pred, rbb_angle_version, rbb_edge, rbb_angle
     n, dim = sph_gt.shape
     if variant == 'legacy' and dim == 5:
         raise ValueError('sph2pob_legacy supports BFoV (n, 4) boxes only')
-    b1, b2 = G.as_f32(sph_gt.detach()), G.as_f32(sph_pred.detach())
-    o1 = torch.empty((n, 5), dtype=torch.float32, device=b1.device)
-    o2 = torch.empty((n, 5), dtype=torch.float32, device=b1.device)
-    if n:
-        G.call('sph2pob_transform_f32', b1.device, G.ptr(b1), G.ptr(b2), G.ptr(o1), G.ptr(o2), ctypes.c_int64(n),
-               dim, G.VARIANTS[variant], G.EDGES[rbb_edge], G.ANGLES.get(rbb_angle, 0), int(bool(jitter)),
-               G.stream_of(b1))
+    o1, o2 = _Sph2PobTransformFunction.apply(sph_gt, sph_pred, variant, rbb_edge, rbb_angle, jitter)
     if rbb_angle_version == 'deg':
-        o1[:, 4] = torch.rad2deg(o1[:, 4])
-        o2[:, 4] = torch.rad2deg(o2[:, 4])
+        o1 = torch.cat([o1[:, :4], torch.rad2deg(o1[:, 4:])], dim=1)
+        o2 = torch.cat([o2[:, :4], torch.rad2deg(o2[:, 4:])], dim=1)
     return o1, o2
 
 

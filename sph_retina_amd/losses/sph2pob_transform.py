@@ -3,8 +3,10 @@ an OBB loss's `forward` so that spherical boxes are transformed to planar orient
 
 Here the three steps the reference runs as ~70 torch launches (spherical jitter, sph2pob transform, rotated jitter,
 :26-30) are ONE kernel launch (`sph2pob_transform_f32(..., jitter=1)`).  It serves the wrapped OBB losses that are
-not fused end-to-end (L1 / GD / KF bodies are mmrotate math: SURVEY §8f-3); note that this path returns planar
-boxes without an autograd graph, so it is for loss VALUES and for callers that only need the transform.
+not fused end-to-end (L1 / GD / KF bodies are mmrotate math: SURVEY §8f-3).  The returned planar boxes carry an
+autograd node whose backward is ONE kernel (`sph2pob_transform_bwd_f32`, the closed-form adjoint of the transform
+and of both jitters' clamp gates), so any torch OBB loss body wrapped by this decorator back-propagates to the
+spherical inputs exactly like the reference's autograd does through ~70 recorded ops.
 `Sph2PobIoULoss` does not use it: it is fused end to end with its own backward (sph2pob_iou_loss.py here).
 """
 import functools

@@ -138,3 +138,39 @@ def test_config3_size_1m_rbfov_ciou_fwd_bwd(L, oracle):
     tol = 3e-2 * np.abs(an) + 3e-4
     assert (err > tol).mean() < 0.02, ((err > tol).mean(), np.median(err), np.median(np.abs(an)))
     assert np.median(err) < 1e-4, np.median(err)
+
+
+def test_sph2pob_transform_decorator_is_differentiable(L, oracle):
+    """Any torch OBB loss body wrapped by Sph2PobTransfrom (sphdet/losses/sph2pob_transform.py:11-37) back-propagates
+    to the spherical inputs through the HIP transform adjoint; checked against the oracle (values) and f64 finite
+    differences (gradients)."""
+    import torch.nn as nn
+
+    @L.Sph2PobTransfrom()
+    class SmoothPlanarL1(nn.Module):
+        def forward(self, pred, target, weight=None):
+            d = pred - target
+            cols = torch.tensor([0, 2, 3, 4], device=d.device)       # y is a constant of the transform
+            return torch.sqrt(d[:, cols] ** 2 + 1e-2).sum()
+
+    g = load_golden('loss_rbfov')
+    sl = slice(0, 200)
+    pred, target = cu(g['pred'][sl], True), cu(g['target'][sl], True)
+    loss = SmoothPlanarL1()(pred, target)
+    loss.backward()
+    p1, p2 = oracle.transform(g['pred'][sl], g['target'][sl], variant='standard', jitter=True, dtype=np.float64)
+    d = (p1 - p2)[:, [0, 2, 3, 4]]
+    np.testing.assert_allclose(loss.item(), np.sqrt(d ** 2 + 1e-2).sum(), rtol=2e-5)
+    gd = np.zeros_like(p1)
+    gd[:, [0, 2, 3, 4]] = d / np.sqrt(d ** 2 + 1e-2)
+    want = oracle.transform_vjp_fd(g['pred'][sl], g['target'][sl], gd, -gd, variant='standard', jitter=True)
+    for mine, ref in ((pred.grad, want[0]), (target.grad, want[1])):
+        e = np.abs(mine.cpu().numpy() - ref)
+        scale = np.abs(ref).max()
+        assert np.median(e) < 2e-4 * scale and (e > 0.02 * scale).mean() < 0.02, (np.median(e), scale)
+    # plain transforms are differentiable too (efficient variant, no jitter), degrees output keeps the graph
+    from sph_retina_amd.iou import sph2pob_efficient
+    p = cu(g['pred'][sl], True)
+    o1, o2 = sph2pob_efficient(p, cu(g['target'][sl]), rbb_angle_version='deg')
+    (o2[:, 0].sum() + o1[:, 4].sum()).backward()
+    assert p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().sum()) > 0

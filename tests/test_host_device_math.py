@@ -82,3 +82,25 @@ def test_loss_adjoint_vs_fp64_finite_differences(host_harness, oracle, box, fast
             scale = np.abs(fd).max()
             assert np.median(d) < 2e-4 * scale, (mode, np.median(d), scale)
             assert (d > 0.05 * scale).mean() < 0.03, (mode, (d > 0.05 * scale).mean())
+
+
+@pytest.mark.parametrize('variant', ['standard', 'efficient'])
+@pytest.mark.parametrize('box', ['bfov', 'rbfov'])
+@pytest.mark.parametrize('edge,jitter', [('arc', True), ('arc', False), ('chord', True), ('tangent', False)])
+def test_transform_adjoint_vs_fp64_finite_differences(host_harness, oracle, variant, box, edge, jitter):
+    """The closed-form adjoint of sph2pob_{standard,efficient} (what makes every Sph2Pob-wrapped OBB loss
+    differentiable) against f64 central differences of the oracle's transform (no shared code)."""
+    g = load_golden('loss_' + box)
+    sl = slice(0, 200)
+    rng = np.random.default_rng(3)
+    g1 = rng.standard_normal((200, 5)).astype(np.float32)
+    g2 = rng.standard_normal((200, 5)).astype(np.float32)
+    g1[:, 1] = 0  # y is a constant of the transform in exact arithmetic (pi/2 | 0): the reference's autograd sends
+    g2[:, 1] = 0  # only rounding noise through it
+    mine = host_harness.transform_bwd(g['pred'][sl], g['target'][sl], g1, g2, variant=variant, edge=edge, jitter=jitter)
+    want = oracle.transform_vjp_fd(g['pred'][sl], g['target'][sl], g1, g2, variant=variant, edge=edge, jitter=jitter)
+    for a, b in zip(mine, want):
+        d = np.abs(a - b)
+        scale = np.abs(b).max()
+        assert np.median(d) < 2e-4 * scale, (np.median(d), scale)
+        assert (d > 0.02 * scale).mean() < 0.02, (d > 0.02 * scale).mean()
