@@ -40,6 +40,12 @@ def _sph2pob_iou_auxiliary(bboxes1, bboxes2, variant, mode, is_aligned, calculat
     if variant == 'legacy' and dim == 5:
         # the reference raises ValueError from torch.chunk(…, 4) on 5 columns: sph2pob_legacy.py:52-53
         raise ValueError('sph2pob_legacy supports BFoV (n, 4) boxes only')
+    if (calculator == 'diff' and is_aligned and variant == 'standard' and mode == 'iou' and rbb_edge == 'arc'
+            and rbb_angle == 'equator' and torch.is_grad_enabled() and (bboxes1.requires_grad or bboxes2.requires_grad)):
+        # the differentiable route the reference intended for SphIoULoss (sph2pob_iou_loss.py:292 passes
+        # calculator='diff'): IoU = 1 - (IoU-mode loss element), gradients from the fused loss backward kernel
+        from ..losses.sph2pob_iou_loss import sph2pob_iou_loss
+        return 1.0 - sph2pob_iou_loss(bboxes1, bboxes2, mode='iou', reduction='none')
     b1, b2 = G.as_f32(bboxes1.detach()), G.as_f32(bboxes2.detach())
     if is_aligned:
         assert rows == cols

@@ -174,3 +174,18 @@ def test_sph2pob_transform_decorator_is_differentiable(L, oracle):
     o1, o2 = sph2pob_efficient(p, cu(g['target'][sl]), rbb_angle_version='deg')
     (o2[:, 0].sum() + o1[:, 4].sum()).backward()
     assert p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().sum()) > 0
+
+
+def test_diff_calculator_is_autograd_capable(L):
+    """`calculator='diff'` (a NameError in the reference at HEAD, sph_iou_api.py:14,81) returns the same IoU as
+    'common' and carries gradients when asked to."""
+    import sph_retina_amd as S
+    g = load_golden('loss_bfov')
+    p, t = cu(g['pred'], True), cu(g['target'])
+    iou = S.sph2pob_standard_iou(p, t, is_aligned=True, calculator='diff')
+    common = S.sph2pob_standard_iou(p.detach(), t, is_aligned=True)
+    assert float((iou.detach() - common).abs().max()) < 1e-5
+    (1 - iou).sum().backward()
+    ref = g['gpred_iou']
+    d = np.abs(p.grad.cpu().numpy() - ref)
+    assert np.median(d) < 1e-6 * np.abs(ref).max() and d.max() < 5e-3 * np.abs(ref).max()
