@@ -14,7 +14,7 @@ import torch
 
 from ... import _lib
 from ... import _torch_glue as G
-from ...registry import build_iou_calculator
+from ...registry import BBOX_ASSIGNERS, build_iou_calculator
 
 
 class AssignResult:
@@ -69,6 +69,7 @@ def assign_wrt_overlaps(overlaps, gt_labels=None, pos_iou_thr=0.5, neg_iou_thr=0
     return res
 
 
+@BBOX_ASSIGNERS.register_module()
 class SphMaxIoUAssigner:
     """Same constructor as mmdet's MaxIoUAssigner (:45-65); `iou_calculator` defaults to the Sph2Pob standard IoU."""
 

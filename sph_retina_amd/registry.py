@@ -46,6 +46,7 @@ def _mmdet_registry(path, attr, local_name):
 IOU_CALCULATORS, IOU_CALCULATORS_IS_MMDET = _mmdet_registry('mmdet.core.bbox.iou_calculators.builder',
                                                             'IOU_CALCULATORS', 'iou_calculator')
 LOSSES, LOSSES_IS_MMDET = _mmdet_registry('mmdet.models.builder', 'LOSSES', 'loss')
+BBOX_ASSIGNERS, BBOX_ASSIGNERS_IS_MMDET = _mmdet_registry('mmdet.core.bbox.builder', 'BBOX_ASSIGNERS', 'bbox_assigner')
 
 
 def build_iou_calculator(cfg, default_args=None):
@@ -56,3 +57,8 @@ def build_iou_calculator(cfg, default_args=None):
 def build_loss(cfg):
     return LOSSES.build(cfg) if not LOSSES_IS_MMDET else \
         __import__('mmdet.models.builder', fromlist=['x']).build_loss(cfg)
+
+
+def build_assigner(cfg):
+    return BBOX_ASSIGNERS.build(cfg) if not BBOX_ASSIGNERS_IS_MMDET else \
+        __import__('mmdet.core.bbox.builder', fromlist=['x']).build_assigner(cfg)
