@@ -5,8 +5,12 @@
 
 One "step" = one pass of the hot path over one batch of synthetic boxes resident in HBM:
 aligned `sph2pob_standard_iou` over 1,000,000 BFoV pairs per GPU (BASELINE.json configs[1]); for N > 1 every
-rank owns its own 1 M-pair shard (N = 8 is configs[4]: 8 M pairs sharded 8x) and the per-shard IoU vectors are
-assembled on every rank with ONE RCCL all_gather_into_tensor on the compute stream, inside the timed step.
+rank owns its own 1 M-pair shard (N = 8: the 8 M pairs of configs[4] sharded 8x).  Box pairs are independent, so the
+path shards with NO data-path collective: results stay on the rank that owns the shard (their consumers — assigner,
+loss, NMS — are sharded the same way).  `--gather` additionally assembles the per-shard IoU vectors on every rank with
+one RCCL all_gather_into_tensor per step, double-buffered so that the collective of step i (RCCL's stream) overlaps
+the kernel of step i+1 (4 MB per rank per step: wire + launch time of the collective exceeds the 10 us kernel, so that
+variant is communication-bound by construction).
 `value` = pairs processed by all ranks / max-over-ranks wall time.  Weak scaling (per-GPU work fixed).
 
 Extra objects on the JSON line:
@@ -90,6 +94,10 @@ def main():
     ap.add_argument('--arithmetic', default='fast', choices=['fast', 'reference'],
                     help="'fast' = default closed-form core; 'reference' = the reference's fp32 operation order")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--gather', action='store_true',
+                    help='N > 1: also assemble the per-shard IoU vectors on every rank with one RCCL all-gather per step '
+                         '(pipelined one step deep); default: shards stay on their ranks, no data-path collective')
+    ap.add_argument('--force-dist', action='store_true', help='initialise the process group even with one rank (tests)')
     args = ap.parse_args()
 
     import torch
@@ -110,42 +118,60 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    gather = use_dist and args.gather
 
     n = args.pairs
     b1 = make_boxes(n, 2 * rank, dev)        # rank r owns its own contiguous shard, generated per rank
     b2 = make_boxes(n, 2 * rank + 1, dev)
-    gathered = torch.empty(world * n, dtype=torch.float32, device=dev) if world > 1 else None
-    shard = torch.empty(n, dtype=torch.float32, device=dev)   # this rank's IoU vector (pre-allocated)
+    # this rank's IoU vector and the assembled vector, double-buffered so that the RCCL all-gather of step i (on the
+    # process group's own stream) overlaps the kernel of step i+1 (pre-allocated)
+    shards = [torch.empty(n, dtype=torch.float32, device=dev) for _ in range(2 if gather else 1)]
+    gathered = [torch.empty(world * n, dtype=torch.float32, device=dev) for _ in range(2)] if gather else None
+    shard = shards[0]
+    pending = [None, None]
     lib = _lib.lib()
     stream = torch.cuda.current_stream(dev)
     G.set_arithmetic(args.arithmetic)
     variant_c = G.VARIANTS[args.variant]
 
-    def step():
-        rc = lib.sph2pob_iou_aligned_f32(G.ptr(b1), G.ptr(b2), G.ptr(shard), ctypes.c_int64(n), 4, variant_c, 0, 0, 0,
+    def step(i):
+        k = i & 1 if gather else 0
+        if gather and pending[k] is not None:
+            pending[k].wait()          # stream-ordered: the kernel below waits for the collective that read shards[k]
+        rc = lib.sph2pob_iou_aligned_f32(G.ptr(b1), G.ptr(b2), G.ptr(shards[k]), ctypes.c_int64(n), 4, variant_c, 0, 0, 0,
                                          ctypes.c_void_p(stream.cuda_stream))
         if rc:
             _lib.check(rc, 'sph2pob_iou_aligned_f32')
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, shard)
+        if gather:
+            pending[k] = dist.all_gather_into_tensor(gathered[k], shards[k], async_op=True)
+
+    def drain():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
 
     def barrier():
-        if world > 1:
+        drain()
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -177,8 +203,8 @@ def main():
             'dtype': 'f32',
             'data': 'synthetic',
             'config': {'workload': f'{n:,} uniform random BFoV pairs per GPU, sph2pob_{args.variant}_iou aligned '
-                                   f'(BASELINE configs[1]{"; x%d shards + RCCL all-gather = configs[4]" % world if world > 1 else ""})',
-                       'pairs_per_gpu': n, 'variant': args.variant, 'arithmetic': args.arithmetic, 'parallelism': f'shard{world}'},
+                                   f'(BASELINE configs[1]{"; x%d shards" % world if world > 1 else ""}{" + RCCL all-gather of the shards, pipelined one step deep" if gather else ""})',
+                       'pairs_per_gpu': n, 'variant': args.variant, 'arithmetic': args.arithmetic, 'parallelism': f'shard{world}', 'gather': bool(gather)},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(),
                          'kernel': 'iou_aligned_compact_kernel' if args.arithmetic == 'fast' and args.variant != 'legacy'
@@ -190,7 +216,7 @@ def main():
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
