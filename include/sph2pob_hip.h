@@ -23,7 +23,10 @@ extern "C" {
 #endif
 
 /* transform variant: sphdet/iou/sph_iou_api.py:91-98 (sph2pob_{standard,efficient,legacy}_iou) */
-enum { SPH2POB_VARIANT_STANDARD = 0, SPH2POB_VARIANT_EFFICIENT = 1, SPH2POB_VARIANT_LEGACY = 2 };
+enum { SPH2POB_VARIANT_STANDARD = 0, SPH2POB_VARIANT_EFFICIENT = 1, SPH2POB_VARIANT_LEGACY = 2,
+       /* the cheap approximate backends of SphOverlaps2D (sphdet/iou/sph_iou_api.py:128-175; BFoV, mode 'iou' only):
+        * Sph-IoU and FoV-IoU closed forms of sphdet/iou/approximate_ious.py:3-54 — SURVEY §8f-4 */
+       SPH2POB_VARIANT_SPH_IOU = 3, SPH2POB_VARIANT_FOV_IOU = 4 };
 /* OR-ed into `variant`: evaluate the transform in the reference's own fp32 operation order (bit-for-bit the
  * arithmetic of sph2pob_standard.py / sph2pob_efficient.py, ~3x the VALU work) instead of the closed-form core.
  * Both meet the parity bar on the benchmark distribution; on close-centre pairs the closed-form core is ~10x

@@ -208,5 +208,25 @@ def main():
     save('nms', **arrs)
 
 
+def approx_only():
+    """Sph-IoU / FoV-IoU fixtures (sphdet/iou/sph_iou_api.py:128-175): own seed, does not touch the other files."""
+    torch.manual_seed(20231025)
+    g, p = gen(1500)
+    gn, pn = gen(1500, near=True)
+    b1, b2 = torch.cat([g, gn]), torch.cat([p, pn])
+    a, _ = gen(6)
+    b, _ = gen(9)
+    b[:6] = a + torch.randn(6, 4) * 3
+    b[:, 1] = b[:, 1].clamp(1, 179)
+    b[:, 2:] = b[:, 2:].clamp(1, 170)
+    save('approx', b1=b1, b2=b2, sph_iou=R.api.sph_iou(b1, b2, is_aligned=True), fov_iou=R.api.fov_iou(b1, b2, is_aligned=True),
+         sph_iou64=f64(R.api.sph_iou, b1, b2, is_aligned=True), fov_iou64=f64(R.api.fov_iou, b1, b2, is_aligned=True),
+         pa=a, pb=b, sph_iou_pw=R.api.sph_iou(a, b), fov_iou_pw=R.api.fov_iou(a, b))
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'approx':
+        approx_only()
+    else:
+        main()
+        approx_only()

@@ -18,7 +18,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, '_build', 'libsph2pob_oracle.so')
 
-VARIANTS = {'standard': 0, 'efficient': 1, 'legacy': 2}
+VARIANTS = {'standard': 0, 'efficient': 1, 'legacy': 2, 'sph_iou': 3, 'fov_iou': 4}
 MODES = {'iou': 0, 'iof': 1}
 EDGES = {'arc': 0, 'chord': 1, 'tangent': 2}
 ANGLES = {'equator': 0, 'project': 1, None: 0}

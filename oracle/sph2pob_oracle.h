@@ -4,7 +4,8 @@
 #define SPH2POB_ORACLE_H
 #include <stdint.h>
 
-enum { SPH2POB_VARIANT_STANDARD = 0, SPH2POB_VARIANT_EFFICIENT = 1, SPH2POB_VARIANT_LEGACY = 2 };
+enum { SPH2POB_VARIANT_STANDARD = 0, SPH2POB_VARIANT_EFFICIENT = 1, SPH2POB_VARIANT_LEGACY = 2,
+       SPH2POB_VARIANT_SPH_IOU = 3, SPH2POB_VARIANT_FOV_IOU = 4 };
 enum { SPH2POB_MODE_IOU = 0, SPH2POB_MODE_IOF = 1 };
 enum { SPH2POB_EDGE_ARC = 0, SPH2POB_EDGE_CHORD = 1, SPH2POB_EDGE_TANGENT = 2 };
 enum { SPH2POB_ANGLE_EQUATOR = 0, SPH2POB_ANGLE_PROJECT = 1 };

@@ -574,6 +574,38 @@ static REAL FN(planar_iou)(const FN(pbox)* b1, const FN(pbox)* b2, int mode, int
     return planar == SPH2POB_PLANAR_MMCV ? FN(planar_iou_mmcv)(b1, b2, mode) : FN(planar_iou_diff)(b1, b2, mode);
 }
 
+static inline REAL FN(rmin)(REAL a, REAL b) { return a < b ? a : b; }
+static inline REAL FN(rmax)(REAL a, REAL b) { return a > b ? a : b; }
+
+/* Sph-IoU / FoV-IoU closed forms: sphdet/iou/approximate_ious.py:3-54 (inputs after the spherical jitter). */
+static REAL FN(approx_iou)(const REAL* g_, const REAL* p_, int fov) {
+    REAL g0 = g_[0], p0 = p_[0];
+    REAL dt = g0 - p0;
+    dt = dt < 0 ? -dt : dt;
+    if (dt > R_(180)) { /* standardize_spherical_box :59-79 */
+        g0 = (REAL)MFMOD(g0 + R_(180), R_(360));
+        p0 = (REAL)MFMOD(p0 + R_(180), R_(360));
+    }
+    const REAL pi = R_(3.141592653589793), hpi = R_(3.141592653589793 / 2);
+    REAL thg = FN(deg2rad)(g0) - pi, phg = hpi - FN(deg2rad)(g_[1]);   /* angle2radian 'convention' :81-99 */
+    REAL thp = FN(deg2rad)(p0) - pi, php = hpi - FN(deg2rad)(p_[1]);
+    REAL ag = FN(deg2rad)(g_[2]), bg = FN(deg2rad)(g_[3]), ap = FN(deg2rad)(p_[2]), bp = FN(deg2rad)(p_[3]);
+    REAL ag2 = ag / R_(2), bg2 = bg / R_(2), ap2 = ap / R_(2), bp2 = bp / R_(2);
+    REAL tmin, tmax;
+    if (fov) {
+        REAL delta = (thp - thg) * FN(rcos)((phg + php) / R_(2));
+        tmin = FN(rmax)(-ag2, delta - ap2);
+        tmax = FN(rmin)(ag2, delta + ap2);
+    } else {
+        tmin = FN(rmax)(thg - ag2, thp - ap2);
+        tmax = FN(rmin)(thg + ag2, thp + ap2);
+    }
+    REAL pmin = FN(rmax)(phg - bg2, php - bp2), pmax = FN(rmin)(phg + bg2, php + bp2);
+    REAL ai = FN(rmax)(tmax - tmin, 0) * FN(rmax)(pmax - pmin, 0);
+    REAL au = ag * bg + ap * bp - ai;
+    return ai / (au + R_(1e-8));
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 /* _sph2pob_iou_auxiliary for ONE pair: sphdet/iou/sph_iou_api.py:48-86 */
 static REAL FN(pair_iou)(const REAL* b1_, const REAL* b2_, int dim, int variant, int mode, int edge, int angle,
@@ -581,6 +613,8 @@ static REAL FN(pair_iou)(const REAL* b1_, const REAL* b2_, int dim, int variant,
     REAL b1[5], b2[5];
     for (int k = 0; k < dim; k++) { b1[k] = b1_[k]; b2[k] = b2_[k]; }
     FN(jitter_spherical)(b1, b2, dim);
+    if (variant == SPH2POB_VARIANT_SPH_IOU || variant == SPH2POB_VARIANT_FOV_IOU) /* sph_iou_api.py:128-175 */
+        return FN(clampr)(FN(approx_iou)(b1, b2, variant == SPH2POB_VARIANT_FOV_IOU), 0, 1);
     FN(pbox) p1, p2;
     FN(transform_dispatch)(variant, b1, b2, dim, edge, angle, &p1, &p2);
     FN(jitter_rotated)(&p1, &p2);
@@ -595,9 +629,6 @@ static void FN(obb2hbb)(const FN(pbox)* b, REAL out[4]) {
     REAL W = ca * b->w + sa * b->h, H = sa * b->w + ca * b->h;
     out[0] = b->x - W / R_(2); out[1] = b->y - H / R_(2); out[2] = b->x + W / R_(2); out[3] = b->y + H / R_(2);
 }
-static inline REAL FN(rmin)(REAL a, REAL b) { return a < b ? a : b; }
-static inline REAL FN(rmax)(REAL a, REAL b) { return a > b ? a : b; }
-
 /* Sph2PobTransfrom.new_forward + obb_iou_loss for ONE pair, unweighted element loss.
  * sphdet/losses/sph2pob_transform.py:24-35 ; sphdet/losses/sph2pob_iou_loss.py:104-196 */
 static REAL FN(pair_loss)(const REAL* pred_, const REAL* target_, int dim, int loss_mode, double eps_, REAL* iou_out) {
@@ -641,7 +672,7 @@ static REAL FN(pair_loss)(const REAL* pred_, const REAL* target_, int dim, int l
 static int FN(iou_aligned)(const REAL* b1, const REAL* b2, REAL* out, int64_t n, int dim, int variant, int mode,
                            int edge, int angle, int planar, int nthreads) {
     if (dim != 4 && dim != 5) return SPH2POB_ERR_DIM;
-    if (variant == SPH2POB_VARIANT_LEGACY && dim == 5) return SPH2POB_ERR_DIM;
+    if (variant >= SPH2POB_VARIANT_LEGACY && dim == 5) return SPH2POB_ERR_DIM;
     (void)nthreads;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
@@ -652,7 +683,7 @@ static int FN(iou_aligned)(const REAL* b1, const REAL* b2, REAL* out, int64_t n,
 static int FN(iou_pairwise)(const REAL* b1, int64_t m, const REAL* b2, int64_t n, REAL* out, int dim, int variant,
                             int mode, int edge, int angle, int planar, int nthreads) {
     if (dim != 4 && dim != 5) return SPH2POB_ERR_DIM;
-    if (variant == SPH2POB_VARIANT_LEGACY && dim == 5) return SPH2POB_ERR_DIM;
+    if (variant >= SPH2POB_VARIANT_LEGACY && dim == 5) return SPH2POB_ERR_DIM;
     (void)nthreads;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)

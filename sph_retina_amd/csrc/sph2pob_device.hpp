@@ -21,7 +21,7 @@
 
 namespace sph2pob {
 
-enum : int { VARIANT_STANDARD = 0, VARIANT_EFFICIENT = 1, VARIANT_LEGACY = 2 };
+enum : int { VARIANT_STANDARD = 0, VARIANT_EFFICIENT = 1, VARIANT_LEGACY = 2, VARIANT_SPH_IOU = 3, VARIANT_FOV_IOU = 4 };
 enum : int { MODE_IOU = 0, MODE_IOF = 1 };
 enum : int { EDGE_ARC = 0, EDGE_CHORD = 1, EDGE_TANGENT = 2 };
 enum : int { ANGLE_EQUATOR = 0, ANGLE_PROJECT = 1 };
@@ -262,7 +262,7 @@ template <int VARIANT, int DIM>
 SPH_DEV void transform(const float (&g)[5], const float (&p)[5], int edge, int angle, PBox& og, PBox& op) {
     if (VARIANT == VARIANT_STANDARD) transform_standard<DIM>(g, p, edge, angle, og, op);
     else if (VARIANT == VARIANT_EFFICIENT) transform_efficient<DIM>(g, p, edge, angle, og, op);
-    else transform_legacy(g, p, edge, og, op);
+    else if (VARIANT == VARIANT_LEGACY) transform_legacy(g, p, edge, og, op);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -324,6 +324,36 @@ SPH_DEV float planar_iou(const PBox& A, const PBox& B, int mode) {
     return inter / base;
 }
 
+// Sph-IoU / FoV-IoU closed forms (sphdet/iou/approximate_ious.py:3-54) on spherically jittered boxes: the two cheap
+// approximate backends of SphOverlaps2D (sph_iou_api.py:128-175).  ~40 VALU per pair: the one genuinely HBM-bound
+// operator of the package.
+template <bool FOV>
+SPH_DEV float approx_iou(const float (&g_)[5], const float (&p_)[5]) {
+    float g0 = g_[0], p0 = p_[0];
+    if (fabsf(g0 - p0) > 180.0f) {  // standardize_spherical_box :59-79
+        g0 = fmodf(g0 + 180.0f, 360.0f);
+        p0 = fmodf(p0 + 180.0f, 360.0f);
+    }
+    const float hpi = (float)(3.141592653589793 / 2);
+    float thg = g0 * kDeg2Rad - kPi, phg = hpi - g_[1] * kDeg2Rad;  // angle2radian 'convention' :81-99
+    float thp = p0 * kDeg2Rad - kPi, php = hpi - p_[1] * kDeg2Rad;
+    float ag = g_[2] * kDeg2Rad, bg = g_[3] * kDeg2Rad, ap = p_[2] * kDeg2Rad, bp = p_[3] * kDeg2Rad;
+    float ag2 = ag / 2.0f, bg2 = bg / 2.0f, ap2 = ap / 2.0f, bp2 = bp / 2.0f;
+    float tmin, tmax;
+    if (FOV) {
+        float delta = (thp - thg) * cosf((phg + php) / 2.0f);
+        tmin = fmaxf(-ag2, delta - ap2);
+        tmax = fminf(ag2, delta + ap2);
+    } else {
+        tmin = fmaxf(thg - ag2, thp - ap2);
+        tmax = fminf(thg + ag2, thp + ap2);
+    }
+    float pmin = fmaxf(phg - bg2, php - bp2), pmax = fminf(phg + bg2, php + bp2);
+    float ai = fmaxf(tmax - tmin, 0.0f) * fmaxf(pmax - pmin, 0.0f);
+    float au = ag * bg + ap * bp - ai;
+    return ai / (au + 1e-8f);
+}
+
 // _sph2pob_iou_auxiliary for one pair — sph_iou_api.py:48-86
 template <int VARIANT, int DIM>
 SPH_DEV float pair_iou(const float (&in1)[5], const float (&in2)[5], int mode, int edge, int angle) {
@@ -331,6 +361,8 @@ SPH_DEV float pair_iou(const float (&in1)[5], const float (&in2)[5], int mode, i
 #pragma unroll
     for (int k = 0; k < 5; k++) { b1[k] = in1[k]; b2[k] = in2[k]; }
     jitter_spherical<DIM>(b1, b2);
+    if (VARIANT == VARIANT_SPH_IOU || VARIANT == VARIANT_FOV_IOU)
+        return fminf(fmaxf(approx_iou<VARIANT == VARIANT_FOV_IOU>(b1, b2), 0.0f), 1.0f);
     PBox p1, p2;
     transform<VARIANT, DIM>(b1, b2, edge, angle, p1, p2);
     jitter_rotated(p1, p2);

@@ -556,8 +556,8 @@ int check_common(int box_dim, int variant_flags, int edge, int angle) {
     const int variant = variant_flags & 0xff;
     if (variant_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER)) return SPH2POB_ERR_OPTION;
     if (box_dim != 4 && box_dim != 5) return SPH2POB_ERR_DIM;
-    if (variant < 0 || variant > 2 || edge < 0 || edge > 2 || angle < 0 || angle > 1) return SPH2POB_ERR_OPTION;
-    if (variant == SPH2POB_VARIANT_LEGACY && box_dim == 5) return SPH2POB_ERR_DIM;
+    if (variant < 0 || variant > 4 || edge < 0 || edge > 2 || angle < 0 || angle > 1) return SPH2POB_ERR_OPTION;
+    if (variant >= SPH2POB_VARIANT_LEGACY && box_dim == 5) return SPH2POB_ERR_DIM;  // BFoV-only variants
     return SPH2POB_OK;
 }
 
@@ -573,6 +573,8 @@ int dispatch(int variant_flags, int box_dim, F&& f) {
     f.fast = !(variant_flags & SPH2POB_FLAG_REFERENCE_ORDER);
     if (variant == SPH2POB_VARIANT_STANDARD) return box_dim == 4 ? f.template run<0, 4>() : f.template run<0, 5>();
     if (variant == SPH2POB_VARIANT_EFFICIENT) return box_dim == 4 ? f.template run<1, 4>() : f.template run<1, 5>();
+    if (variant == SPH2POB_VARIANT_SPH_IOU) return f.template run<3, 4>();
+    if (variant == SPH2POB_VARIANT_FOV_IOU) return f.template run<4, 4>();
     return f.template run<2, 4>();
 }
 
@@ -580,18 +582,18 @@ struct AlignedLaunch {
     const float *b1, *b2; float* out; int64_t n; int mode, edge, angle; hipStream_t s; bool fast = true;
     template <int V, int D> int run() {
         dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-        if (fast && V != 2 && angle == SPH2POB_ANGLE_EQUATOR && n < ((int64_t)1 << 31) - 64 && !g_no_compact) {
+        if (fast && V < 2 && angle == SPH2POB_ANGLE_EQUATOR && n < ((int64_t)1 << 31) - 64 && !g_no_compact) {
             // persistent-style grid: enough slices per wave for the survivor stacks to fill
             int64_t slices = (n + 63) / 64;
             int64_t wgs = (slices + 4 * g_slices_per_wave - 1) / (4 * g_slices_per_wave);
             if (wgs > 256 * 7) wgs = 256 * 7;
             if (wgs < 1) wgs = 1;
             if (g_prefetch)
-                hipLaunchKernelGGL((iou_aligned_compact_kernel<V == 2 ? 0 : V, D, true>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge);
+                hipLaunchKernelGGL((iou_aligned_compact_kernel<V >= 2 ? 0 : V, D, true>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge);
             else
-                hipLaunchKernelGGL((iou_aligned_compact_kernel<V == 2 ? 0 : V, D, false>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge);
-        } else if (fast && V != 2 && angle == SPH2POB_ANGLE_EQUATOR)
-            hipLaunchKernelGGL((iou_aligned_kernel<V == 2 ? 0 : V, D, true>), grid, dim3(kBlock), 0, s, b1, b2, out, n, mode, edge, angle);
+                hipLaunchKernelGGL((iou_aligned_compact_kernel<V >= 2 ? 0 : V, D, false>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge);
+        } else if (fast && V < 2 && angle == SPH2POB_ANGLE_EQUATOR)
+            hipLaunchKernelGGL((iou_aligned_kernel<V >= 2 ? 0 : V, D, true>), grid, dim3(kBlock), 0, s, b1, b2, out, n, mode, edge, angle);
         else
             hipLaunchKernelGGL((iou_aligned_kernel<V, D, false>), grid, dim3(kBlock), 0, s, b1, b2, out, n, mode, edge, angle);
         return launch_status();
@@ -600,7 +602,7 @@ struct AlignedLaunch {
 struct PairwiseLaunch {
     const float* b1; int64_t m; const float* b2; int64_t n; float* out; int mode, edge, angle; hipStream_t s; bool fast = true;
     template <int V, int D> int run() {
-        if (fast && V != 2 && angle == SPH2POB_ANGLE_EQUATOR && n < ((int64_t)1 << 31) - kBlock && m <= (int64_t)65535 * 4 &&
+        if (fast && V < 2 && angle == SPH2POB_ANGLE_EQUATOR && n < ((int64_t)1 << 31) - kBlock && m <= (int64_t)65535 * 4 &&
             !g_no_compact) {
             // rows per workgroup: as many as possible (amortises the per-column setup, fills the survivor stacks) while
             // the grid still holds >= ~8 workgroups per CU
@@ -610,7 +612,7 @@ struct PairwiseLaunch {
             if (rpw > kPwRows) rpw = kPwRows;
             if (rpw > m) rpw = m;
             dim3 grid((unsigned)col_tiles, (unsigned)((m + rpw - 1) / rpw));
-            hipLaunchKernelGGL((iou_pairwise_compact_kernel<V == 2 ? 0 : V, D>), grid, dim3(kBlock), 0, s, b1, (int)m, b2, (int)n,
+            hipLaunchKernelGGL((iou_pairwise_compact_kernel<V >= 2 ? 0 : V, D>), grid, dim3(kBlock), 0, s, b1, (int)m, b2, (int)n,
                                out, mode, edge, (int)rpw);
             return launch_status();
         }
@@ -619,8 +621,8 @@ struct PairwiseLaunch {
         for (int64_t r0 = 0; r0 < m; r0 += kMaxRows) {
             int64_t rows = m - r0 < kMaxRows ? m - r0 : kMaxRows;
             dim3 grid((unsigned)((n + kBlock - 1) / kBlock), (unsigned)rows);
-            if (fast && V != 2 && angle == SPH2POB_ANGLE_EQUATOR)
-                hipLaunchKernelGGL((iou_pairwise_kernel<V == 2 ? 0 : V, D, true>), grid, dim3(kBlock), 0, s, b1 + r0 * D, rows,
+            if (fast && V < 2 && angle == SPH2POB_ANGLE_EQUATOR)
+                hipLaunchKernelGGL((iou_pairwise_kernel<V >= 2 ? 0 : V, D, true>), grid, dim3(kBlock), 0, s, b1 + r0 * D, rows,
                                    b2, n, out + r0 * n, mode, edge, angle);
             else
                 hipLaunchKernelGGL((iou_pairwise_kernel<V, D, false>), grid, dim3(kBlock), 0, s, b1 + r0 * D, rows, b2, n,

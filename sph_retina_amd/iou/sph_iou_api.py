@@ -37,9 +37,9 @@ def _sph2pob_iou_auxiliary(bboxes1, bboxes2, variant, mode, is_aligned, calculat
     if bboxes2.size(1) != dim or dim not in (4, 5):
         raise ValueError(f'boxes must both be (n, 4) BFoV or (n, 5) RBFoV, got {tuple(bboxes1.shape)} and '
                          f'{tuple(bboxes2.shape)}')
-    if variant == 'legacy' and dim == 5:
+    if variant in ('legacy', 'sph_iou', 'fov_iou') and dim == 5:
         # the reference raises ValueError from torch.chunk(…, 4) on 5 columns: sph2pob_legacy.py:52-53
-        raise ValueError('sph2pob_legacy supports BFoV (n, 4) boxes only')
+        raise ValueError(f'{variant} supports BFoV (n, 4) boxes only')
     if (calculator == 'diff' and is_aligned and variant == 'standard' and mode == 'iou' and rbb_edge == 'arc'
             and rbb_angle == 'equator' and torch.is_grad_enabled() and (bboxes1.requires_grad or bboxes2.requires_grad)):
         # the differentiable route the reference intended for SphIoULoss (sph2pob_iou_loss.py:292 passes
@@ -58,6 +58,18 @@ def _sph2pob_iou_auxiliary(bboxes1, bboxes2, variant, mode, is_aligned, calculat
                ctypes.c_int64(cols), G.ptr(out), dim, G.VARIANTS[variant], mode_c, edge_c, angle_c,
                G.stream_of(b1))
     return out if bboxes1.dtype == torch.float32 else out.to(bboxes1.dtype)
+
+
+def sph_iou(bboxes1, bboxes2, mode='iou', is_aligned=False, calculator='diff'):
+    """Sph-IoU (AAAI-2020 closed form), reference sph_iou_api.py:128-150: jitter -> sph_iou_aligned -> clamp."""
+    assert mode in ['iou']
+    return _sph2pob_iou_auxiliary(bboxes1, bboxes2, 'sph_iou', 'iou', is_aligned, 'common', 'arc', 'equator')
+
+
+def fov_iou(bboxes1, bboxes2, mode='iou', is_aligned=False, calculator='diff'):
+    """FoV-IoU (arXiv 2202.03176 closed form), reference sph_iou_api.py:155-175."""
+    assert mode in ['iou']
+    return _sph2pob_iou_auxiliary(bboxes1, bboxes2, 'fov_iou', 'iou', is_aligned, 'common', 'arc', 'equator')
 
 
 def sph2pob_legacy_iou(bboxes1, bboxes2, mode='iou', is_aligned=False, calculator='common', rbb_edge='arc'):

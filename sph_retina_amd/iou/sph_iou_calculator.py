@@ -7,12 +7,12 @@
 import torch
 
 from ..registry import IOU_CALCULATORS
-from .sph_iou_api import sph2pob_efficient_iou, sph2pob_legacy_iou, sph2pob_standard_iou
+from .sph_iou_api import fov_iou, sph2pob_efficient_iou, sph2pob_legacy_iou, sph2pob_standard_iou, sph_iou
 
 _ALL_BACKENDS = ['unbiased_iou', 'sph2pob_standard_iou', 'sph2pob_legacy_iou', 'sph2pob_efficient_iou', 'naive_iou',
                  'fov_iou', 'sph_iou', 'kent_iou']
 _HIP_BACKENDS = {'sph2pob_standard_iou': sph2pob_standard_iou, 'sph2pob_legacy_iou': sph2pob_legacy_iou,
-                 'sph2pob_efficient_iou': sph2pob_efficient_iou}
+                 'sph2pob_efficient_iou': sph2pob_efficient_iou, 'sph_iou': sph_iou, 'fov_iou': fov_iou}
 
 
 @IOU_CALCULATORS.register_module()

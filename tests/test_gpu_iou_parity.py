@@ -258,3 +258,22 @@ def test_full_size_properties_1m(S, oracle, arith):
     idx = torch.randperm(n, device='cuda')[:20000]
     ref = oracle.iou_aligned(b1[idx].cpu().numpy(), b2[idx].cpu().numpy(), variant='efficient', planar='mmcv')
     assert np.abs(iou[idx].cpu().numpy() - ref).mean() < 1e-6
+
+
+def test_cheap_backends_sph_iou_fov_iou(S, oracle):
+    """Sph-IoU / FoV-IoU (sphdet/iou/approximate_ious.py) served through the same registry: fixtures from the reference."""
+    g = load_golden('approx')
+    t1, t2 = torch.from_numpy(g['b1']).cuda(), torch.from_numpy(g['b2']).cuda()
+    for name in ('sph_iou', 'fov_iou'):
+        fn = getattr(S.iou, name)
+        got = fn(t1, t2, is_aligned=True).cpu().numpy()
+        np.testing.assert_allclose(got, g[name], atol=2e-6)       # element-wise closed forms: a few ulps
+        np.testing.assert_allclose(got, oracle.iou_aligned(g['b1'], g['b2'], variant=name), atol=2e-6)
+        pw = fn(torch.from_numpy(g['pa']).cuda(), torch.from_numpy(g['pb']).cuda()).cpu().numpy()
+        np.testing.assert_allclose(pw, g[name + '_pw'], atol=2e-6)
+        calc = S.SphOverlaps2D(backend=name, box_version=4)
+        np.testing.assert_array_equal(calc(t1[:50], t2[:70]).cpu().numpy(), fn(t1[:50], t2[:70]).cpu().numpy())
+        with pytest.raises(AssertionError):
+            fn(t1, t2, mode='iof')
+        with pytest.raises(ValueError):
+            fn(torch.rand(3, 5, device='cuda'), torch.rand(3, 5, device='cuda'))

@@ -175,3 +175,12 @@ def test_nms_keep_lists(oracle):
     dets, keep = oracle.batched_nms(g['r5boxes'], g['r5scores'], g['r5idxs'], 0.4)
     assert keep.tolist() == g['r5keep'].tolist()
     np.testing.assert_allclose(dets, g['r5dets'], atol=1e-6)
+
+
+def test_cheap_backends_sph_iou_fov_iou(oracle):
+    """Sph-IoU / FoV-IoU closed forms (sphdet/iou/approximate_ious.py:3-54 behind sph_iou_api.py:128-175)."""
+    g = load_golden('approx')
+    for v in ('sph_iou', 'fov_iou'):
+        np.testing.assert_allclose(oracle.iou_aligned(g['b1'], g['b2'], variant=v), g[v], atol=3e-7)
+        np.testing.assert_allclose(oracle.iou_aligned(g['b1'], g['b2'], variant=v, dtype=np.float64), g[v + '64'], atol=1e-12)
+        np.testing.assert_allclose(oracle.iou_pairwise(g['pa'], g['pb'], variant=v), g[v + '_pw'], atol=3e-7)
