@@ -249,10 +249,10 @@ SPH_DEV void fast_planar(const FastRec& r, PlanarPair& o) {
     o.g_A = A > Amin;
     A = fmaxf(A, Amin);
     float ca = r.D * iS, sa = r.N * iS, cb = r.Dp * iS, sb = r.Np * iS;
-    if (S2 < 1e-13f) {
-        // coincident (or exactly antipodal) centres: the bearing is undefined — the reference's own value is
-        // rounding noise of c_g x c_p, or its degenerate-branch frame (sph2pob_standard.py:286-297) in which both
-        // meridian tangents sit at +pi/2.  Use that frame: a = pi/2 for both boxes.
+    if (!(S2 > 1e-30f)) {
+        // exactly coincident (or exactly antipodal) centres: the bearing is undefined (0/0).  N and D are products,
+        // not differences, so they stay meaningful down to ~1e-15 (e.g. two boxes clamped onto a pole: A ~ 1e-7 but
+        // the bearings still differ by the longitude difference); only a literal zero needs a convention: a = pi/2.
         ca = 0.0f; sa = 1.0f; cb = 0.0f; sb = 1.0f;
     }
     if (DIM == 5) {
