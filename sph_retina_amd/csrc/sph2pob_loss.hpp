@@ -31,8 +31,10 @@ SPH_DEV ClipIv clip_iv(float px, float py, float iux, float iuy, float len, floa
     float ay = (-hy - py) * iuy, by = (hy - py) * iuy;
     float lo = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), 0.0f);
     float hi = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), len);
-    hi = fmaxf(hi, lo);
-    return ClipIv{lo, hi};
+    // empty interval (also lo = +inf for an edge parallel to and outside a slab): collapse to [0, 0] so that the
+    // length and the rotation term (hi + lo - len) * (hi - lo) stay finite
+    const bool empty = !(hi > lo);
+    return ClipIv{empty ? 0.0f : lo, empty ? 0.0f : hi};
 }
 
 // intersection area + its gradient w.r.t. one rectangle's own (centre-along-its-axes, w, h, a)
@@ -231,7 +233,8 @@ SPH_DEV float pair_loss(const float (&pred)[5], const float (&target)[5], int lo
 
     // ---- planar IoU (value of mmcv diff_iou_rotated_2d: sphdet/iou/diff_iou_rotated.py:325-343) ----
     float c = ca * cb + sa * sb, s = sa * cb - ca * sb;
-    float ic = 1.0f / c, is = 1.0f / s;
+    // clamped reciprocals: exactly parallel edges (s == 0 after the jitter bumps) give finite, correctly ordered bounds
+    float ic = fminf(fmaxf(1.0f / c, -1e18f), 1e18f), is = fminf(fmaxf(1.0f / s, -1e18f), 1e18f);
     float hwa = 0.5f * P.w, hha = 0.5f * P.h, hwb = 0.5f * T.w, hhb = 0.5f * T.h;
     float pax = -(dx * cb + dy * sb), pay = -(dy * cb - dx * sb);
     float pbx = dx * ca + dy * sa, pby = dy * ca - dx * sa;
