@@ -156,6 +156,31 @@ int sph2pob_assign_f32(const float* overlaps, int64_t k, int64_t n, float pos_io
                        int64_t* gt_argmax_overlaps, int64_t* assigned_gt_inds, int64_t* assigned_labels, void* workspace,
                        void* stream);
 
+/* ---- box coder: the step immediately in front of the loss when reg_decoded_bbox=True --------------
+ * Replaces sphdet/bbox/coder/delta_xywh_sph_bbox_coder.py:116-161 (bbox2delta), :164-263 (delta2bbox) for box_dim 4
+ * and sphdet/bbox/coder/delta_xywha_rsph_bbox_coder.py:116-164, :167-268 for box_dim 5 (fifth delta = deg2rad of the
+ * gamma difference; decoded gamma clamped to [-90+1e-7, 90-1e-7]).
+ *
+ * means / stds: HOST pointers to box_dim floats (copied into the kernel arguments; NULL = zeros / ones).
+ * encode : deltas[i] = ((gt - proposal) / size, log(size ratio)[, deg2rad(dgamma)] - means) / stds, widths clipped at 1e-7.
+ * decode : rois (n, box_dim), deltas (n, num_classes*box_dim) -> boxes (n, num_classes*box_dim);
+ *          flags: SPH2POB_CODER_CLIP_BORDER (clamp to the sphere ranges, the reference's clip_border=True),
+ *                 SPH2POB_CODER_CTR_CLAMP  (add_ctr_clamp=True: centre shift clamped to +-ctr_clamp, dwh only from above);
+ *          max_ratio = |log(wh_ratio_clip)|.
+ * decode_bwd: grad_deltas = J^T grad_boxes with the clamp gates of decode (what autograd gives the reference when the
+ *          decoded boxes feed Sph2PobIoULoss: sphdet/models/heads/sph_retina_head.py:255-264).
+ */
+enum { SPH2POB_CODER_CLIP_BORDER = 1, SPH2POB_CODER_CTR_CLAMP = 2 };
+int sph2pob_coder_encode_f32(const float* proposals, const float* gt, const float* means_host, const float* stds_host,
+                             float* deltas, int64_t n, int box_dim, void* stream);
+int sph2pob_coder_decode_f32(const float* rois, const float* deltas, const float* means_host, const float* stds_host,
+                             float* boxes, int64_t n, int num_classes, int box_dim, float max_ratio, int flags,
+                             float ctr_clamp, void* stream);
+int sph2pob_coder_decode_bwd_f32(const float* rois, const float* deltas, const float* grad_boxes,
+                                 const float* means_host, const float* stds_host, float* grad_deltas, int64_t n,
+                                 int num_classes, int box_dim, float max_ratio, int flags, float ctr_clamp,
+                                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -224,9 +224,49 @@ def approx_only():
          pa=a, pb=b, sph_iou_pw=R.api.sph_iou(a, b), fov_iou_pw=R.api.fov_iou(a, b))
 
 
+def coder_only():
+    """Box-coder fixtures (sphdet/bbox/coder/delta_xywh_sph_bbox_coder.py, delta_xywha_rsph_bbox_coder.py): encode,
+    decode (single and multi-class, both clamp modes) and the autograd gradient of decode w.r.t. the deltas."""
+    torch.manual_seed(20231026)
+    arrs = {}
+    for dim, mod, cls in ((4, R.coder4, 'DeltaXYWHSphBBoxCoder'), (5, R.coder5, 'DeltaXYWHASphBBoxCoder')):
+        n = 600
+        anchors, gts = gen(n, box='bfov' if dim == 4 else 'rbfov', near=True)
+        anchors[:5, 2] = 0.0                                    # width clip at eps
+        means = (0.01, -0.02, 0.03, 0.0, 0.05)[:dim]
+        stds = (0.1, 0.1, 0.2, 0.2, 0.1)[:dim]
+        coder = getattr(mod, cls)(target_means=means, target_stds=stds)
+        enc = coder.encode(anchors, gts)
+        deltas = torch.randn(n, dim) * torch.tensor((1.0, 1.0, 1.5, 1.5, 3.0)[:dim])
+        deltas[:40] *= 4                                         # drive the ratio clip and the border clamp
+        deltas[40:60, 2:4] = 25.0
+        dreq = deltas.clone().requires_grad_(True)
+        dec = coder.decode(anchors, dreq)
+        gout = torch.randn(n, dim)
+        (dec * gout).sum().backward()
+        ctr = getattr(mod, cls)(target_means=means, target_stds=stds, add_ctr_clamp=True, ctr_clamp=6, clip_border=False)
+        dreq2 = deltas.clone().requires_grad_(True)
+        dec_ctr = ctr.decode(anchors, dreq2, wh_ratio_clip=0.05)
+        (dec_ctr * gout).sum().backward()
+        nc = 3
+        dm = torch.randn(50, nc * dim)
+        dec_mc = mod.delta2bbox(anchors[:50], dm, means, stds)
+        plain = mod.delta2bbox(anchors, deltas)                  # default means / stds
+        rt = mod.delta2bbox(anchors[5:], mod.bbox2delta(anchors[5:], gts[5:]))  # round trip
+        k = f'd{dim}_'
+        arrs.update({k + 'anchors': anchors, k + 'gts': gts, k + 'means': torch.tensor(means), k + 'stds': torch.tensor(stds),
+                     k + 'enc': enc, k + 'deltas': deltas, k + 'dec': dec.detach(), k + 'gout': gout,
+                     k + 'gdeltas': dreq.grad, k + 'dec_ctr': dec_ctr.detach(), k + 'gdeltas_ctr': dreq2.grad,
+                     k + 'deltas_mc': dm, k + 'dec_mc': dec_mc, k + 'dec_plain': plain, k + 'roundtrip': rt})
+    save('coder', **arrs)
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'approx':
         approx_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'coder':
+        coder_only()
     else:
         main()
         approx_only()
+        coder_only()

@@ -295,3 +295,74 @@ def generate_boxes(n, seed, box='bfov', alpha=(1, 100), beta=(1, 100), gamma=(-9
     if box == 'rbfov':
         cols.append(u[:, 4] * (gamma[1] - gamma[0]) + gamma[0])
     return np.stack(cols, axis=1).astype(np.float32)
+
+
+# ---- box coders: numpy restatement ------------------------------------------------------------------
+def coder_encode(proposals, gt, means=None, stds=None, dtype=np.float32):
+    """bbox2delta — sphdet/bbox/coder/delta_xywh_sph_bbox_coder.py:116-161 (4 columns) and
+    delta_xywha_rsph_bbox_coder.py:116-164 (5 columns: fifth delta = deg2rad(gamma_gt - gamma_proposal))."""
+    p = np.asarray(proposals, dtype=dtype)
+    g = np.asarray(gt, dtype=dtype)
+    dim = p.shape[-1]
+    eps = dtype(1e-7)
+    pw, ph = np.maximum(p[..., 2], eps), np.maximum(p[..., 3], eps)
+    gw, gh = np.maximum(g[..., 2], eps), np.maximum(g[..., 3], eps)
+    cols = [(g[..., 0] - p[..., 0]) / pw, (g[..., 1] - p[..., 1]) / ph, np.log(gw / pw), np.log(gh / ph)]
+    if dim == 5:
+        cols.append((g[..., 4] - p[..., 4]) * dtype(np.pi / 180.0))
+    d = np.stack(cols, axis=-1).astype(dtype)
+    m = np.zeros(dim, dtype) if means is None else np.asarray(means, dtype)
+    s = np.ones(dim, dtype) if stds is None else np.asarray(stds, dtype)
+    return ((d - m) / s).astype(dtype)
+
+
+def coder_decode(rois, deltas, means=None, stds=None, wh_ratio_clip=16 / 1000, clip_border=True, add_ctr_clamp=False,
+                 ctr_clamp=32, box_dim=None, dtype=np.float32, grad_boxes=None):
+    """delta2bbox — delta_xywh_sph_bbox_coder.py:164-263 / delta_xywha_rsph_bbox_coder.py:167-268.
+    With `grad_boxes` also returns J^T grad_boxes w.r.t. `deltas` (torch.clamp passes gradients on [min, max])."""
+    r = np.asarray(rois, dtype=dtype)
+    dl = np.asarray(deltas, dtype=dtype)
+    dim = r.shape[-1] if box_dim is None else box_dim
+    n = dl.shape[0]
+    nc = dl.shape[1] // dim
+    if n == 0:
+        return dl if grad_boxes is None else (dl, dl)
+    m = np.zeros(dim, dtype) if means is None else np.asarray(means, dtype)
+    s = np.ones(dim, dtype) if stds is None else np.asarray(stds, dtype)
+    d = dl.reshape(-1, dim) * s + m
+    p = np.repeat(r, nc, axis=0)
+    eps = dtype(1e-7)
+    max_ratio = dtype(abs(np.log(wh_ratio_clip)))
+    sxy = p[:, 2:4] * d[:, 0:2]
+    dwh = d[:, 2:4]
+    g_s = np.ones_like(sxy)
+    if add_ctr_clamp:
+        c = dtype(ctr_clamp)
+        g_s = ((sxy >= -c) & (sxy <= c)).astype(dtype)
+        sxy = np.clip(sxy, -c, c)
+        g_r = (dwh <= max_ratio).astype(dtype)
+        dwh = np.minimum(dwh, max_ratio)
+    else:
+        g_r = ((dwh >= -max_ratio) & (dwh <= max_ratio)).astype(dtype)
+        dwh = np.clip(dwh, -max_ratio, max_ratio)
+    xy = p[:, 0:2] + sxy
+    wh = p[:, 2:4] * np.exp(dwh)
+    cols = [xy[:, 0], xy[:, 1], wh[:, 0], wh[:, 1]]
+    if dim == 5:
+        cols.append(p[:, 4] + d[:, 4] * dtype(180.0 / np.pi))
+    b = np.stack(cols, axis=-1).astype(dtype)
+    jac = np.empty_like(b)
+    jac[:, 0:2] = g_s * p[:, 2:4] * s[0:2]
+    jac[:, 2:4] = g_r * wh * s[2:4]
+    if dim == 5:
+        jac[:, 4] = dtype(180.0 / np.pi) * s[4]
+    if clip_border:
+        lo = np.array([eps, eps, eps, eps, dtype(-90.0 + 1e-7)][:dim], dtype)
+        hi = np.array([dtype(360.0 - 1e-7), dtype(180.0 - 1e-7), dtype(180.0 - 1e-7), dtype(180.0 - 1e-7),
+                       dtype(90.0 - 1e-7)][:dim], dtype)
+        jac = jac * ((b >= lo) & (b <= hi))
+        b = np.clip(b, lo, hi)
+    b = b.reshape(n, -1)
+    if grad_boxes is None:
+        return b
+    return b, (np.asarray(grad_boxes, dtype).reshape(-1, dim) * jac).reshape(n, -1).astype(dtype)

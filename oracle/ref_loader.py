@@ -127,9 +127,19 @@ def load_reference():
     il = _load('sphdet.losses.sph2pob_iou_loss', 'sphdet/losses/sph2pob_iou_loss.py')
     nms = _load('sphdet.bbox.nms.sph_nms', 'sphdet/bbox/nms/sph_nms.py')
     gen = _load('ref_tests_generate_data', 'tests/utils/generate_data.py')
+    # box coders: the vendored mmdet base class + a no-op registry
+    for name in ['mmdet.core', 'mmdet.core.bbox', 'mmdet.core.bbox.coder']:
+        sys.modules.setdefault(name, types.ModuleType(name))
+    _load('mmdet.core.bbox.coder.base_bbox_coder', 'mmdet/core/bbox/coder/base_bbox_coder.py')
+    cb = types.ModuleType('mmdet.core.bbox.builder')
+    cb.BBOX_CODERS = _Reg()
+    sys.modules['mmdet.core.bbox.builder'] = cb
+    _pkg('sphdet.bbox.coder', 'sphdet/bbox/coder')
+    coder4 = _load('sphdet.bbox.coder.delta_xywh_sph_bbox_coder', 'sphdet/bbox/coder/delta_xywh_sph_bbox_coder.py')
+    coder5 = _load('sphdet.bbox.coder.delta_xywha_rsph_bbox_coder', 'sphdet/bbox/coder/delta_xywha_rsph_bbox_coder.py')
 
     ns = types.SimpleNamespace(
         api=api, std=std, eff=eff, leg=leg, diff=diff, box_formator=box_formator, transform=tr, iou_loss=il,
-        nms=nms, gen=gen, loss_utils=lutils)
+        nms=nms, gen=gen, loss_utils=lutils, coder4=coder4, coder5=coder5)
     _CACHE['ns'] = ns
     return ns

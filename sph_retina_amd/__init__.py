@@ -8,5 +8,6 @@ from .iou import (SphOverlaps2D, sph2pob_efficient_iou, sph2pob_legacy_iou, sph2
 from .losses import Sph2PobIoULoss, SphIoULoss  # noqa: F401,E402
 from .bbox.nms import SphNMS, multiclass_nms  # noqa: F401,E402
 from .bbox.assigners import SphMaxIoUAssigner  # noqa: F401,E402
+from .bbox.coder import DeltaXYWHASphBBoxCoder, DeltaXYWHSphBBoxCoder  # noqa: F401,E402
 
 __version__ = '0.1.0'

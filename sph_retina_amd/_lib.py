@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_DIR = os.path.join(_HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libsph2pob_hip.so')
-SOURCES = ['sph2pob_kernels.hip']
+SOURCES = ['sph2pob_kernels.hip', 'sph2pob_coder.hip']
 HEADERS = ['sph2pob_device.hpp', 'sph2pob_loss.hpp', 'sph2pob_fast.hpp', os.path.join('..', '..', 'include', 'sph2pob_hip.h')]
 # -fno-slp-vectorize: hipcc otherwise pairs scalar fp32 mul/add into v_pk_* (+ v_mov shuffles); packed fp32 issues at
 # half the rate of plain VALU on gfx950 (tools/ubench/valu_rate2.hip), measured 12 % slower on the dominant kernel
@@ -50,6 +50,12 @@ SIGNATURES = {
     'sph2pob_nms_workspace_bytes': [_i64],
     'sph2pob_nms_f32': [_c_f32p, ctypes.c_void_p, _i64, _int, _int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
                         ctypes.c_void_p],
+    'sph2pob_coder_encode_f32': [_c_f32p, _c_f32p, ctypes.c_void_p, ctypes.c_void_p, _c_f32p, _i64, _int,
+                                 ctypes.c_void_p],
+    'sph2pob_coder_decode_f32': [_c_f32p, _c_f32p, ctypes.c_void_p, ctypes.c_void_p, _c_f32p, _i64, _int, _int,
+                                 ctypes.c_float, _int, ctypes.c_float, ctypes.c_void_p],
+    'sph2pob_coder_decode_bwd_f32': [_c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p, ctypes.c_void_p, _c_f32p, _i64, _int,
+                                     _int, ctypes.c_float, _int, ctypes.c_float, ctypes.c_void_p],
 }
 _RESTYPES = {'sph2pob_target_arch': ctypes.c_char_p, 'sph2pob_error_string': ctypes.c_char_p,
              'sph2pob_nms_workspace_bytes': ctypes.c_int64, 'sph2pob_assign_workspace_bytes': ctypes.c_int64}

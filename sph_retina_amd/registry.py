@@ -47,6 +47,7 @@ IOU_CALCULATORS, IOU_CALCULATORS_IS_MMDET = _mmdet_registry('mmdet.core.bbox.iou
                                                             'IOU_CALCULATORS', 'iou_calculator')
 LOSSES, LOSSES_IS_MMDET = _mmdet_registry('mmdet.models.builder', 'LOSSES', 'loss')
 BBOX_ASSIGNERS, BBOX_ASSIGNERS_IS_MMDET = _mmdet_registry('mmdet.core.bbox.builder', 'BBOX_ASSIGNERS', 'bbox_assigner')
+BBOX_CODERS, BBOX_CODERS_IS_MMDET = _mmdet_registry('mmdet.core.bbox.builder', 'BBOX_CODERS', 'bbox_coder')
 
 
 def build_iou_calculator(cfg, default_args=None):
@@ -62,3 +63,8 @@ def build_loss(cfg):
 def build_assigner(cfg):
     return BBOX_ASSIGNERS.build(cfg) if not BBOX_ASSIGNERS_IS_MMDET else \
         __import__('mmdet.core.bbox.builder', fromlist=['x']).build_assigner(cfg)
+
+
+def build_bbox_coder(cfg):
+    return BBOX_CODERS.build(cfg) if not BBOX_CODERS_IS_MMDET else \
+        __import__('mmdet.core.bbox.builder', fromlist=['x']).build_bbox_coder(cfg)

@@ -135,6 +135,32 @@ def config4():
             'nms_5000x37cls_ms': t_nms * 1e3, 'nms_5000_single_class_ms': t_nms1 * 1e3}
 
 
+def coder(n=1_000_000):
+    """§8f-2: decode (the op in front of loss_bbox) and encode on n RBFoV / BFoV boxes, via the C ABI."""
+    import ctypes
+    from sph_retina_amd import _lib, _torch_glue as G
+    lib = _lib.lib()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = {'config': 'box coder, %d boxes (sph2pob_coder_*_f32 through the C ABI)' % n}
+    for dim in (4, 5):
+        a, g = boxes(n, 3, dim).contiguous(), boxes(n, 4, dim).contiguous()
+        d = torch.randn((n, dim), device='cuda')
+        o, go = torch.empty_like(d), torch.randn((n, dim), device='cuda')
+        stds = (ctypes.c_float * dim)(*([0.1, 0.1, 0.2, 0.2, 0.1][:dim]))
+        nn, mr = ctypes.c_int64(n), ctypes.c_float(abs(math.log(16 / 1000)))
+        te = timeit(lambda: lib.sph2pob_coder_encode_f32(G.ptr(a), G.ptr(g), None, stds, G.ptr(o), nn, dim, st), reps=100)
+        td = timeit(lambda: lib.sph2pob_coder_decode_f32(G.ptr(a), G.ptr(d), None, stds, G.ptr(o), nn, 1, dim, mr, 1,
+                                                         ctypes.c_float(32), st), reps=100)
+        tb = timeit(lambda: lib.sph2pob_coder_decode_bwd_f32(G.ptr(a), G.ptr(d), G.ptr(go), None, stds, G.ptr(o), nn, 1, dim,
+                                                             mr, 1, ctypes.c_float(32), st), reps=100)
+        bpb = 4 * dim
+        out['dim%d' % dim] = {'encode_us': te * 1e6, 'decode_us': td * 1e6, 'decode_bwd_us': tb * 1e6,
+                              'bytes_per_box': {'encode': 3 * bpb, 'decode': 3 * bpb, 'decode_bwd': 4 * bpb},
+                              'hbm_GBps': {'encode': 3 * bpb * n / te / 1e9, 'decode': 3 * bpb * n / td / 1e9,
+                                           'decode_bwd': 4 * bpb * n / tb / 1e9}}
+    return out
+
+
 if __name__ == '__main__':
-    for fn in (config3, config4):
+    for fn in (config3, config4, coder):
         print(json.dumps(fn()), flush=True)
