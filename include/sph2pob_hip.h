@@ -26,7 +26,16 @@ extern "C" {
 enum { SPH2POB_VARIANT_STANDARD = 0, SPH2POB_VARIANT_EFFICIENT = 1, SPH2POB_VARIANT_LEGACY = 2,
        /* the cheap approximate backends of SphOverlaps2D (sphdet/iou/sph_iou_api.py:128-175; BFoV, mode 'iou' only):
         * Sph-IoU and FoV-IoU closed forms of sphdet/iou/approximate_ious.py:3-54 — SURVEY §8f-4 */
-       SPH2POB_VARIANT_SPH_IOU = 3, SPH2POB_VARIANT_FOV_IOU = 4 };
+       SPH2POB_VARIANT_SPH_IOU = 3, SPH2POB_VARIANT_FOV_IOU = 4,
+       /* Unbiased IoU: exact spherical-polygon intersection area, BFoV and RBFoV, mode 'iou' only —
+        * sphdet/iou/sph_iou_api.py:103-126 over unbiased_iou_bfov.py:4-204 / unbiased_iou_rbfov.py:4-182 (numpy on the
+        * CPU in the reference; the default backend of SphOverlaps2D and an SphNMS calculator, sph_nms.py:11-12).
+        * Double precision on the device.  With SPH2POB_FLAG_REFERENCE_ORDER it also reproduces the fp32 roundings
+        * numpy applies to fp32 inputs (noisier: the reference's fp32 areas cancel catastrophically on small boxes). */
+       SPH2POB_VARIANT_UNBIASED = 5,
+       /* Naive IoU: planar IoU of the boxes in ERP pixel space (sph_iou_api.py:179-197; sph_nms.py:13-14), BFoV via
+        * axis-aligned boxes, RBFoV via rotated boxes; no jitter, mode 'iou' only */
+       SPH2POB_VARIANT_NAIVE = 6 };
 /* OR-ed into `variant`: evaluate the transform in the reference's own fp32 operation order (bit-for-bit the
  * arithmetic of sph2pob_standard.py / sph2pob_efficient.py, ~3x the VALU work) instead of the closed-form core.
  * Both meet the parity bar on the benchmark distribution; on close-centre pairs the closed-form core is ~10x

@@ -261,8 +261,47 @@ def coder_only():
     save('coder', **arrs)
 
 
+def unbiased_only():
+    """Unbiased-IoU fixtures (sphdet/iou/sph_iou_api.py:103-126 over unbiased_iou_bfov.py / unbiased_iou_rbfov.py): the
+    reference on float32 tensors (its own mixed float32/float64 numpy arithmetic) and on float64 tensors (truth)."""
+    torch.manual_seed(20231027)
+    arrs = {}
+    for box in ('bfov', 'rbfov'):
+        d = 4 if box == 'bfov' else 5
+        g, p = gen(1500, box=box)
+        gn, pn = gen(2500, box=box, near=True)
+        # structured cases: identical, contained, shared edge planes (integer degrees), poles, seam, wide boxes
+        e1 = torch.tensor([[40., 60., 30., 20., 10.], [40., 60., 30., 20., 10.], [10., 90., 20., 20., 0.],
+                           [10., 90., 20., 20., 0.], [359., 90., 30., 30., 5.], [180., 2., 40., 40., -30.],
+                           [90., 178., 50., 30., 45.], [120., 70., 170., 160., 0.], [200., 45., 1., 1., 0.],
+                           [200., 45., 1., 1., 0.], [30., 60., 60., 60., 0.], [300., 120., 90., 10., 80.]])[:, :d]
+        e2 = torch.tensor([[40., 60., 30., 20., 10.], [40., 60., 10., 8., 10.], [30., 90., 20., 20., 0.],
+                           [10., 110., 20., 20., 0.], [1., 92., 30., 30., -5.], [0., 3., 40., 40., 60.],
+                           [270., 177., 50., 30., -45.], [130., 80., 165., 150., 20.], [200.4, 45.3, 1., 1., 0.],
+                           [200., 45., 1.5, 0.5, 30.], [30., 60., 20., 90., 0.], [300., 120., 10., 90., -10.]])[:, :d]
+        ig = torch.floor(g[:400])
+        ip = torch.floor(ig + torch.randint(-6, 7, ig.shape).float())
+        ip[:, 0] = ip[:, 0] % 360
+        ip[:, 1] = ip[:, 1].clamp(1, 179)
+        ip[:, 2:4] = ip[:, 2:4].clamp(1, 170)
+        if d == 5:
+            ip[:, 4] = ip[:, 4].clamp(-89, 89)
+        ig[:, 1] = ig[:, 1].clamp(1, 179)
+        ig[:, 2:4] = ig[:, 2:4].clamp(1, 170)
+        b1, b2 = torch.cat([g, gn, e1, ig]), torch.cat([p, pn, e2, ip])
+        pa, pb = gn[:7].clone(), torch.cat([pn[:5], gn[2:6] + 1.5])
+        arrs.update({box + '_b1': b1, box + '_b2': b2,
+                     box + '_iou32': R.api.unbiased_iou(b1, b2, is_aligned=True),
+                     box + '_iou64': f64(R.api.unbiased_iou, b1, b2, is_aligned=True),
+                     box + '_pa': pa, box + '_pb': pb, box + '_pw32': R.api.unbiased_iou(pa, pb),
+                     box + '_pw64': f64(R.api.unbiased_iou, pa, pb)})
+    save('unbiased', **arrs)
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'approx':
+    if len(sys.argv) > 1 and sys.argv[1] == 'unbiased':
+        unbiased_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'approx':
         approx_only()
     elif len(sys.argv) > 1 and sys.argv[1] == 'coder':
         coder_only()
@@ -270,3 +309,4 @@ if __name__ == '__main__':
         main()
         approx_only()
         coder_only()
+        unbiased_only()

@@ -30,7 +30,7 @@ def build(force=False):
     """Compile the C oracle (gcc).  Building the checker is not using it."""
     if force or not os.path.exists(_SO) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_SO)
-            for f in ('sph2pob_oracle.c', 'sph2pob_oracle_impl.h', 'sph2pob_oracle.h')):
+            for f in ('sph2pob_oracle.c', 'sph2pob_oracle_impl.h', 'sph2pob_oracle.h', 'unbiased_iou_oracle.h')):
         subprocess.check_call(['make', '-C', _HERE, '-s'] + (['-B'] if force else []))
     return _SO
 
@@ -231,7 +231,12 @@ def nms_op(boxes, scores, iou_threshold, variant='efficient', planar='mmcv'):
         keep.append(order[0])
         if order.size == 1:
             break
-        iou = iou_pairwise(boxes[order[:1]], boxes[order[1:]], variant=variant, planar=planar).reshape(-1)
+        if variant == 'unbiased':
+            iou = unbiased_iou(boxes[order[:1]], boxes[order[1:]], is_aligned=False).reshape(-1)
+        elif variant == 'naive':
+            iou = naive_iou(boxes[order[:1]], boxes[order[1:]], is_aligned=False, planar=planar).reshape(-1)
+        else:
+            iou = iou_pairwise(boxes[order[:1]], boxes[order[1:]], variant=variant, planar=planar).reshape(-1)
         order = order[1:][iou <= np.float32(iou_threshold)]
     return np.asarray(keep, dtype=np.int64)
 
@@ -366,3 +371,62 @@ def coder_decode(rois, deltas, means=None, stds=None, wh_ratio_clip=16 / 1000, c
     if grad_boxes is None:
         return b
     return b, (np.asarray(grad_boxes, dtype).reshape(-1, dim) * jac).reshape(n, -1).astype(dtype)
+
+
+# ---- Unbiased IoU (the default backend of SphOverlaps2D and an SphNMS calculator) ---------------------
+UNBIASED_PREC = {'f64': 0, 'kernel': 1, 'reference_f32': 2}
+
+
+def unbiased_iou(b1, b2, is_aligned=True, prec='kernel', nthreads=None):
+    """unbiased_iou — sphdet/iou/sph_iou_api.py:103-126 over unbiased_iou_bfov.py / unbiased_iou_rbfov.py.
+    prec: 'f64' (reference on float64 tensors), 'kernel' (fp32 jitter + deg2rad, then double: what the HIP kernel
+    computes), 'reference_f32' (the reference's mixed numpy arithmetic on float32 tensors)."""
+    a = _np(b1, np.float64)
+    b = _np(b2, np.float64)
+    dim = a.shape[1]
+    if not is_aligned:
+        m, n = a.shape[0], b.shape[0]
+        a, b = np.repeat(a, n, axis=0), np.tile(b, (m, 1))
+    out = np.empty(a.shape[0], np.float64)
+    fn = lib().sph2pob_oracle_unbiased_iou
+    fn.argtypes = [ctypes.POINTER(ctypes.c_double)] * 3 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    rc = fn(_ptr(np.ascontiguousarray(a), ctypes.c_double), _ptr(np.ascontiguousarray(b), ctypes.c_double),
+            _ptr(out, ctypes.c_double), a.shape[0], dim, UNBIASED_PREC[prec], nthreads or max_threads())
+    assert rc == 0, rc
+    out = out.astype(np.float32 if prec != 'f64' else np.float64)
+    return out if is_aligned else out.reshape(m, n)
+
+
+def naive_iou(b1, b2, is_aligned=True, planar='mmcv'):
+    """naive_iou — sphdet/iou/sph_iou_api.py:179-197: Sph2PlanarBoxTransform('sph2pix'), img_size (512, 1024)
+    (sphdet/bbox/box_formator.py:76-83, :161-178) then mmcv.ops.bbox_overlaps (BFoV, xyxy, offset 0) or
+    mmcv.ops.box_iou_rotated (RBFoV, angle = -deg2rad(gamma)).  mmcv-full 1.6.0 is absent: bbox_overlaps is restated
+    from its published kernel (inter / max(a1 + a2 - inter, offset)) — PARITY UNPINNED for the BFoV branch; the RBFoV
+    branch goes through the same planar restatement as the Sph2Pob path (`planar`)."""
+    a = _np(b1, np.float32)
+    b = _np(b2, np.float32)
+    dim = a.shape[1]
+    m, n = a.shape[0], b.shape[0]
+    if not is_aligned:
+        a, b = np.repeat(a, n, axis=0), np.tile(b, (m, 1))
+    f = np.float32
+
+    def pix(x):
+        return np.stack([(x[:, 0] / f(360)) * f(1024), (x[:, 1] / f(180)) * f(512), (x[:, 2] / f(360)) * f(1024),
+                         (x[:, 3] / f(180)) * f(512)], axis=1).astype(f)
+    pa, pb = pix(a), pix(b)
+    if dim == 4:
+        def xyxy(p):
+            return p[:, 0] - p[:, 2] / f(2), p[:, 1] - p[:, 3] / f(2), p[:, 0] + p[:, 2] / f(2), p[:, 1] + p[:, 3] / f(2)
+        ax1, ay1, ax2, ay2 = xyxy(pa)
+        bx1, by1, bx2, by2 = xyxy(pb)
+        iw = np.maximum(np.minimum(ax2, bx2) - np.maximum(ax1, bx1), f(0))
+        ih = np.maximum(np.minimum(ay2, by2) - np.maximum(ay1, by1), f(0))
+        inter = iw * ih
+        with np.errstate(divide='ignore', invalid='ignore'):
+            out = inter / np.maximum((ax2 - ax1) * (ay2 - ay1) + (bx2 - bx1) * (by2 - by1) - inter, f(0))
+    else:
+        ra = np.concatenate([pa, -(a[:, 4:5] * f(np.pi / 180))], axis=1).astype(f)
+        rb = np.concatenate([pb, -(b[:, 4:5] * f(np.pi / 180))], axis=1).astype(f)
+        out = planar_iou(ra, rb, mode='iou', planar=planar)
+    return out if is_aligned else out.reshape(m, n)

@@ -61,6 +61,8 @@
 #undef REAL
 #undef FN
 
+#include "unbiased_iou_oracle.h"
+
 int sph2pob_oracle_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -29,6 +29,9 @@ int sph2pob_oracle_max_threads(void);
                                 double eps, int nthreads);
 SPH2POB_ORACLE_DECL(float, f32)
 SPH2POB_ORACLE_DECL(double, f64)
+/* Unbiased IoU (sphdet/iou/unbiased_iou_{bfov,rbfov}.py + sph_iou_api.py:103-126); prec: see unbiased_iou_oracle.h */
+int sph2pob_oracle_unbiased_iou(const double* b1, const double* b2, double* out, int64_t n, int dim, int prec,
+                                int nthreads);
 #ifdef __cplusplus
 }
 #endif

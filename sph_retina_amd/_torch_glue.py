@@ -8,7 +8,7 @@ from . import _lib
 
 import os
 
-_VARIANT_CODES = {'standard': 0, 'efficient': 1, 'legacy': 2, 'sph_iou': 3, 'fov_iou': 4}
+_VARIANT_CODES = {'standard': 0, 'efficient': 1, 'legacy': 2, 'sph_iou': 3, 'fov_iou': 4, 'unbiased': 5, 'naive': 6}
 FLAG_REFERENCE_ORDER = 0x100
 _ARITHMETIC = os.environ.get('SPH2POB_ARITHMETIC', 'fast')
 

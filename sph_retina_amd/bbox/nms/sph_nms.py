@@ -17,7 +17,8 @@ from ... import _lib
 from ... import _torch_glue as G
 
 _CALCULATORS = {'sph2pob_efficient': 'efficient', 'sph2pob_efficient_iou': 'efficient',
-                'sph2pob_standard': 'standard', 'sph2pob_standard_iou': 'standard'}
+                'sph2pob_standard': 'standard', 'sph2pob_standard_iou': 'standard',
+                'unbiased_iou': 'unbiased', 'naive_iou': 'naive'}  # sph_nms.py:9-14
 
 
 def _nms_sorted(boxes_sorted, cls_sorted, iou_threshold, variant):
@@ -78,9 +79,6 @@ class SphNMS:
     def __init__(self, iou_calculator='sph2pob_efficient'):
         if iou_calculator in _CALCULATORS:
             self.variant = _CALCULATORS[iou_calculator]
-        elif iou_calculator in ('unbiased_iou', 'naive_iou'):
-            raise NotImplementedError(
-                f"SphNMS('{iou_calculator}') is not on the Sph2Pob hot path served by sph_retina_amd (SURVEY §8f-4)")
         else:
             raise TypeError('Not supported iou_calculator.')  # the reference's `raise NotImplemented(...)`
         self.iou_calculator = iou_calculator

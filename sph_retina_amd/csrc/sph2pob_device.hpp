@@ -21,7 +21,8 @@
 
 namespace sph2pob {
 
-enum : int { VARIANT_STANDARD = 0, VARIANT_EFFICIENT = 1, VARIANT_LEGACY = 2, VARIANT_SPH_IOU = 3, VARIANT_FOV_IOU = 4 };
+enum : int { VARIANT_STANDARD = 0, VARIANT_EFFICIENT = 1, VARIANT_LEGACY = 2, VARIANT_SPH_IOU = 3, VARIANT_FOV_IOU = 4,
+             VARIANT_UNBIASED = 5, VARIANT_NAIVE = 6 };
 enum : int { MODE_IOU = 0, MODE_IOF = 1 };
 enum : int { EDGE_ARC = 0, EDGE_CHORD = 1, EDGE_TANGENT = 2 };
 enum : int { ANGLE_EQUATOR = 0, ANGLE_PROJECT = 1 };
@@ -352,6 +353,69 @@ SPH_DEV float approx_iou(const float (&g_)[5], const float (&p_)[5]) {
     float ai = fmaxf(tmax - tmin, 0.0f) * fmaxf(pmax - pmin, 0.0f);
     float au = ag * bg + ap * bp - ai;
     return ai / (au + 1e-8f);
+}
+
+// double-precision twins of clip_len / edges_inside for the jitter-free naive RBFoV stage (transversal edges assumed)
+SPH_DEV double clip_len_d(double px, double py, double ux, double uy, double len, double hx, double hy) {
+    const double iux = 1.0 / ux, iuy = 1.0 / uy;
+    const double ax = (-hx - px) * iux, bx = (hx - px) * iux, ay = (-hy - py) * iuy, by = (hy - py) * iuy;
+    const double lo = fmax(fmax(fmin(ax, bx), fmin(ay, by)), 0.0), hi = fmin(fmin(fmax(ax, bx), fmax(ay, by)), len);
+    return fmax(hi - lo, 0.0);
+}
+SPH_DEV double edges_inside_d(double pax, double pay, double c, double s, double hwa, double hha, double hwb, double hhb,
+                              bool with_origin_terms) {
+    const double ux = hwa * c, uy = hwa * s, vx = -hha * s, vy = hha * c;
+    const double l0 = clip_len_d(pax + ux + vx, pay + uy + vy, -c, -s, 2.0 * hwa, hwb, hhb);
+    const double l1 = clip_len_d(pax - ux + vx, pay - uy + vy, s, -c, 2.0 * hha, hwb, hhb);
+    const double l2 = clip_len_d(pax - ux - vx, pay - uy - vy, c, s, 2.0 * hwa, hwb, hhb);
+    const double l3 = clip_len_d(pax + ux - vx, pay + uy - vy, -s, c, 2.0 * hha, hwb, hhb);
+    if (!with_origin_terms) return hha * (l0 + l2) + hwa * (l1 + l3);
+    const double xu = pax * s - pay * c, xv = pax * c + pay * s;
+    return (l0 * (hha - xu) + l2 * (hha + xu)) + (l1 * (hwa - xv) + l3 * (hwa + xv));
+}
+
+// Naive-IoU (sph_iou_api.py:179-197): boxes mapped to ERP pixels by Sph2PlanarBoxTransform('sph2pix') with the default
+// img_size (512, 1024) (box_formator.py:76-83, :161-178), then mmcv.ops.bbox_overlaps on xyxy (BFoV) or
+// mmcv.ops.box_iou_rotated on (x, y, w, h, -deg2rad(gamma)) (RBFoV).  No jitter and no clamp in the reference.
+// The planar stage has no jitter in front of it here, so exactly parallel rectangles (equal gamma: every
+// BFoV-like detection) are intersected as axis-aligned boxes in their common frame instead of through the
+// edge-crossing integral, which needs transversal edges.
+template <int DIM>
+SPH_DEV float naive_iou(const float (&b1)[5], const float (&b2)[5]) {
+    const float W = 1024.0f, H = 512.0f;
+    const float xa = (b1[0] / 360.0f) * W, ya = (b1[1] / 180.0f) * H, wa = (b1[2] / 360.0f) * W, ha = (b1[3] / 180.0f) * H;
+    const float xb = (b2[0] / 360.0f) * W, yb = (b2[1] / 180.0f) * H, wb = (b2[2] / 360.0f) * W, hb = (b2[3] / 180.0f) * H;
+    if (DIM == 4) {  // xywh2xyxy (box_formator.py:25-31) + bbox_overlaps(mode='iou', aligned, offset=0)
+        const float ax1 = xa - wa / 2.0f, ay1 = ya - ha / 2.0f, ax2 = xa + wa / 2.0f, ay2 = ya + ha / 2.0f;
+        const float bx1 = xb - wb / 2.0f, by1 = yb - hb / 2.0f, bx2 = xb + wb / 2.0f, by2 = yb + hb / 2.0f;
+        const float area_a = (ax2 - ax1) * (ay2 - ay1), area_b = (bx2 - bx1) * (by2 - by1);
+        const float iw = fmaxf(fminf(ax2, bx2) - fmaxf(ax1, bx1), 0.0f), ih = fmaxf(fminf(ay2, by2) - fmaxf(ay1, by1), 0.0f);
+        const float inter = iw * ih;
+        return inter / fmaxf(area_a + area_b - inter, 0.0f);
+    }
+    // Rotated boxes without a jitter in front: near-parallel edges (equal-ish gamma is the common case) make the
+    // edge-crossing integral ill-conditioned in fp32 (1 / sin(delta) amplification), so this stage runs in double.
+    const double aa = -(double)(b1[4] * kDeg2Rad), ab = -(double)(b2[4] * kDeg2Rad);
+    const double sa = sin(aa), ca = cos(aa), sb = sin(ab), cb = cos(ab);
+    const double c = ca * cb + sa * sb, s = sa * cb - ca * sb;
+    const double dx = (double)xb - (double)xa, dy = (double)yb - (double)ya;
+    const double hwa = 0.5 * wa, hha = 0.5 * ha, hwb = 0.5 * wb, hhb = 0.5 * hb;
+    const double pax = -(dx * cb + dy * sb), pay = -(dy * cb - dx * sb);
+    double inter;
+    if (fabs(s) < 1e-12 || fabs(c) < 1e-12) {  // parallel or perpendicular: axis-aligned in B's frame
+        const bool par = fabs(s) < 1e-12;
+        const double ex = par ? hwa : hha, ey = par ? hha : hwa;
+        const double ox = fmax(fmin(pax + ex, hwb) - fmax(pax - ex, -hwb), 0.0);
+        const double oy = fmax(fmin(pay + ey, hhb) - fmax(pay - ey, -hhb), 0.0);
+        inter = ox * oy;
+    } else {
+        const double pbx = dx * ca + dy * sa, pby = dy * ca - dx * sa;
+        const double t = edges_inside_d(pax, pay, c, s, hwa, hha, hwb, hhb, true) +
+                         edges_inside_d(pbx, pby, c, -s, hwb, hhb, hwa, hha, false);
+        inter = 0.5 * fmax(t, 0.0);
+    }
+    const double area = (double)wa * ha + (double)wb * hb;
+    return (float)(inter / (area - inter));
 }
 
 // _sph2pob_iou_auxiliary for one pair — sph_iou_api.py:48-86

@@ -7,6 +7,7 @@
 #include "sph2pob_device.hpp"
 #include "sph2pob_loss.hpp"
 #include "sph2pob_fast.hpp"
+#include "sph2pob_unbiased.hpp"
 
 namespace {
 
@@ -37,7 +38,9 @@ __device__ __forceinline__ void load_box(const float* __restrict__ p, int64_t i,
 // reference-order path of sph2pob_device.hpp (legacy, rbb_angle='project').
 template <int VARIANT, int DIM, bool FAST>
 __device__ __forceinline__ float pair_iou_sel(const float (&x)[5], const float (&y)[5], int mode, int edge, int angle) {
-    if constexpr (FAST) return pair_iou_fast<VARIANT, DIM>(x, y, mode, edge);
+    if constexpr (VARIANT == VARIANT_UNBIASED) return unbiased_pair_iou<DIM, !FAST>(x, y);
+    else if constexpr (VARIANT == VARIANT_NAIVE) return naive_iou<DIM>(x, y);
+    else if constexpr (FAST) return pair_iou_fast<VARIANT, DIM>(x, y, mode, edge);
     else return pair_iou<VARIANT, DIM>(x, y, mode, edge, angle);
 }
 
@@ -266,10 +269,17 @@ __global__ __launch_bounds__(kBlock) void loss_fwd_kernel(const float* __restric
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     float x[5], y[5], gx[5], gy[5], io;
+    const float w = scale * element_weight<DIM>(weight, wd, i);
+    // dense heads pass every anchor with weight 0 on the negatives (sph_retina_head.py:261-264): a wave whose 64
+    // weights are all zero writes its zeros and leaves (loss * 0 == 0 for every finite loss)
+    if (!iou && __ballot(w != 0.0f) == 0) {
+        loss[i] = 0.0f;
+        return;
+    }
     load_box<DIM>(pred, i, x);
     load_box<DIM>(target, i, y);
     float l = pair_loss<DIM, false, FAST>(x, y, loss_mode, eps, &io, gx, gy);
-    loss[i] = l * (scale * element_weight<DIM>(weight, wd, i));
+    loss[i] = l * w;
     if (iou) iou[i] = io;
 }
 
@@ -284,10 +294,15 @@ __global__ __launch_bounds__(kBlock) void loss_bwd_kernel(const float* __restric
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     float x[5], y[5], gx[5], gy[5];
-    load_box<DIM>(pred, i, x);
-    load_box<DIM>(target, i, y);
-    pair_loss<DIM, true, FAST>(x, y, loss_mode, eps, nullptr, gx, gy);
     float g = grad_out[i * grad_stride] * scale * element_weight<DIM>(weight, wd, i);
+    if (__ballot(g != 0.0f) == 0) {  // all-negative wave (see loss_fwd_kernel): zero gradients, no geometry
+#pragma unroll
+        for (int k = 0; k < 5; k++) gx[k] = gy[k] = 0.0f;
+    } else {
+        load_box<DIM>(pred, i, x);
+        load_box<DIM>(target, i, y);
+        pair_loss<DIM, true, FAST>(x, y, loss_mode, eps, nullptr, gx, gy);
+    }
     if (DIM == 4) {
         reinterpret_cast<float4*>(gpred)[i] = make_float4(g * gx[0], g * gx[1], g * gx[2], g * gx[3]);
         if (gtarget) reinterpret_cast<float4*>(gtarget)[i] = make_float4(g * gy[0], g * gy[1], g * gy[2], g * gy[3]);
@@ -556,8 +571,9 @@ int check_common(int box_dim, int variant_flags, int edge, int angle) {
     const int variant = variant_flags & 0xff;
     if (variant_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER)) return SPH2POB_ERR_OPTION;
     if (box_dim != 4 && box_dim != 5) return SPH2POB_ERR_DIM;
-    if (variant < 0 || variant > 4 || edge < 0 || edge > 2 || angle < 0 || angle > 1) return SPH2POB_ERR_OPTION;
-    if (variant >= SPH2POB_VARIANT_LEGACY && box_dim == 5) return SPH2POB_ERR_DIM;  // BFoV-only variants
+    if (variant < 0 || variant > SPH2POB_VARIANT_NAIVE || edge < 0 || edge > 2 || angle < 0 || angle > 1) return SPH2POB_ERR_OPTION;
+    if (variant >= SPH2POB_VARIANT_LEGACY && variant <= SPH2POB_VARIANT_FOV_IOU && box_dim == 5)
+        return SPH2POB_ERR_DIM;  // BFoV-only variants
     return SPH2POB_OK;
 }
 
@@ -575,6 +591,8 @@ int dispatch(int variant_flags, int box_dim, F&& f) {
     if (variant == SPH2POB_VARIANT_EFFICIENT) return box_dim == 4 ? f.template run<1, 4>() : f.template run<1, 5>();
     if (variant == SPH2POB_VARIANT_SPH_IOU) return f.template run<3, 4>();
     if (variant == SPH2POB_VARIANT_FOV_IOU) return f.template run<4, 4>();
+    if (variant == SPH2POB_VARIANT_UNBIASED) return box_dim == 4 ? f.template run<5, 4>() : f.template run<5, 5>();
+    if (variant == SPH2POB_VARIANT_NAIVE) return box_dim == 4 ? f.template run<6, 4>() : f.template run<6, 5>();
     return f.template run<2, 4>();
 }
 
@@ -594,6 +612,8 @@ struct AlignedLaunch {
                 hipLaunchKernelGGL((iou_aligned_compact_kernel<V >= 2 ? 0 : V, D, false>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge);
         } else if (fast && V < 2 && angle == SPH2POB_ANGLE_EQUATOR)
             hipLaunchKernelGGL((iou_aligned_kernel<V >= 2 ? 0 : V, D, true>), grid, dim3(kBlock), 0, s, b1, b2, out, n, mode, edge, angle);
+        else if (V >= 5 && fast)  // unbiased / naive: `fast` selects the default (double) arithmetic of the unbiased IoU
+            hipLaunchKernelGGL((iou_aligned_kernel<V >= 5 ? V : 5, D, true>), grid, dim3(kBlock), 0, s, b1, b2, out, n, mode, edge, angle);
         else
             hipLaunchKernelGGL((iou_aligned_kernel<V, D, false>), grid, dim3(kBlock), 0, s, b1, b2, out, n, mode, edge, angle);
         return launch_status();
@@ -623,6 +643,9 @@ struct PairwiseLaunch {
             dim3 grid((unsigned)((n + kBlock - 1) / kBlock), (unsigned)rows);
             if (fast && V < 2 && angle == SPH2POB_ANGLE_EQUATOR)
                 hipLaunchKernelGGL((iou_pairwise_kernel<V >= 2 ? 0 : V, D, true>), grid, dim3(kBlock), 0, s, b1 + r0 * D, rows,
+                                   b2, n, out + r0 * n, mode, edge, angle);
+            else if (V >= 5 && fast)
+                hipLaunchKernelGGL((iou_pairwise_kernel<V >= 5 ? V : 5, D, true>), grid, dim3(kBlock), 0, s, b1 + r0 * D, rows,
                                    b2, n, out + r0 * n, mode, edge, angle);
             else
                 hipLaunchKernelGGL((iou_pairwise_kernel<V, D, false>), grid, dim3(kBlock), 0, s, b1 + r0 * D, rows, b2, n,
@@ -666,7 +689,7 @@ int sph2pob_iou_aligned_f32(const float* b1, const float* b2, float* out, int64_
                             int mode, int edge, int angle, void* stream) {
     int rc = check_common(box_dim, variant, edge, angle);
     if (rc) return rc;
-    if (mode < 0 || mode > 1) return SPH2POB_ERR_OPTION;
+    if (mode < 0 || mode > 1 || ((variant & 0xff) >= SPH2POB_VARIANT_UNBIASED && mode != SPH2POB_MODE_IOU)) return SPH2POB_ERR_OPTION;
     if (n < 0 || n > kMaxElems) return SPH2POB_ERR_SIZE;
     if (n == 0) return SPH2POB_OK;
     if (!b1 || !b2 || !out) return SPH2POB_ERR_NULL;
@@ -677,7 +700,7 @@ int sph2pob_iou_pairwise_f32(const float* b1, int64_t m, const float* b2, int64_
                              int variant, int mode, int edge, int angle, void* stream) {
     int rc = check_common(box_dim, variant, edge, angle);
     if (rc) return rc;
-    if (mode < 0 || mode > 1) return SPH2POB_ERR_OPTION;
+    if (mode < 0 || mode > 1 || ((variant & 0xff) >= SPH2POB_VARIANT_UNBIASED && mode != SPH2POB_MODE_IOU)) return SPH2POB_ERR_OPTION;
     if (m < 0 || n < 0 || n > kMaxElems || m > kMaxElems) return SPH2POB_ERR_SIZE;
     if (m == 0 || n == 0) return SPH2POB_OK;
     if (!b1 || !b2 || !out) return SPH2POB_ERR_NULL;
@@ -765,7 +788,9 @@ int sph2pob_nms_f32(const float* boxes_sorted, const int64_t* cls_sorted, int64_
     const bool fast = !(variant_flags & SPH2POB_FLAG_REFERENCE_ORDER);
     if (variant_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER)) return SPH2POB_ERR_OPTION;
     if (box_dim != 4 && box_dim != 5) return SPH2POB_ERR_DIM;
-    if (variant != SPH2POB_VARIANT_STANDARD && variant != SPH2POB_VARIANT_EFFICIENT) return SPH2POB_ERR_OPTION;
+    if (variant != SPH2POB_VARIANT_STANDARD && variant != SPH2POB_VARIANT_EFFICIENT && variant != SPH2POB_VARIANT_UNBIASED &&
+        variant != SPH2POB_VARIANT_NAIVE)
+        return SPH2POB_ERR_OPTION;
     if (k < 0 || k > (int64_t)kNmsMaxWords * 64) return SPH2POB_ERR_SIZE;
     if (k == 0) return SPH2POB_OK;
     if (!boxes_sorted || !workspace || !keep) return SPH2POB_ERR_NULL;
@@ -779,6 +804,11 @@ int sph2pob_nms_f32(const float* boxes_sorted, const int64_t* cls_sorted, int64_
     if (variant == SPH2POB_VARIANT_EFFICIENT) {
         if (box_dim == 4) { if (fast) SPH_NMS_LAUNCH(1, 4, true); else SPH_NMS_LAUNCH(1, 4, false); }
         else { if (fast) SPH_NMS_LAUNCH(1, 5, true); else SPH_NMS_LAUNCH(1, 5, false); }
+    } else if (variant == SPH2POB_VARIANT_UNBIASED) {  // sph_nms.py:11-12
+        if (box_dim == 4) { if (fast) SPH_NMS_LAUNCH(5, 4, true); else SPH_NMS_LAUNCH(5, 4, false); }
+        else { if (fast) SPH_NMS_LAUNCH(5, 5, true); else SPH_NMS_LAUNCH(5, 5, false); }
+    } else if (variant == SPH2POB_VARIANT_NAIVE) {     // sph_nms.py:13-14
+        if (box_dim == 4) SPH_NMS_LAUNCH(6, 4, false); else SPH_NMS_LAUNCH(6, 5, false);
     } else {
         if (box_dim == 4) { if (fast) SPH_NMS_LAUNCH(0, 4, true); else SPH_NMS_LAUNCH(0, 4, false); }
         else { if (fast) SPH_NMS_LAUNCH(0, 5, true); else SPH_NMS_LAUNCH(0, 5, false); }

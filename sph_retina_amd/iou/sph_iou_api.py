@@ -72,6 +72,23 @@ def fov_iou(bboxes1, bboxes2, mode='iou', is_aligned=False, calculator='diff'):
     return _sph2pob_iou_auxiliary(bboxes1, bboxes2, 'fov_iou', 'iou', is_aligned, 'common', 'arc', 'equator')
 
 
+def unbiased_iou(bboxes1, bboxes2, mode='iou', is_aligned=False):
+    """Unbiased IoU — exact area of the intersection of two spherical rectangles (BFoV or RBFoV), reference
+    sph_iou_api.py:103-126 over unbiased_iou_bfov.py / unbiased_iou_rbfov.py (numpy on the CPU there; one fp64 HIP
+    kernel here).  `set_arithmetic('reference')` additionally reproduces numpy's fp32 roundings on fp32 inputs."""
+    assert mode in ['iou']
+    return _sph2pob_iou_auxiliary(bboxes1, bboxes2, 'unbiased', 'iou', is_aligned, 'common', 'arc', 'equator')
+
+
+def naive_iou(bboxes1, bboxes2, mode='iou', is_aligned=False, box_formator='sph2pix'):
+    """Naive IoU — planar IoU of the boxes drawn in ERP pixels (reference sph_iou_api.py:179-197): axis-aligned for
+    BFoV (mmcv bbox_overlaps), rotated for RBFoV (mmcv box_iou_rotated); no jitter, no clamp."""
+    assert mode in ['iou']
+    if box_formator != 'sph2pix':  # 'sph2tan' is accepted by Sph2PlanarBoxTransform; no caller in the reference uses it
+        raise NotImplementedError("naive_iou: only box_formator='sph2pix' is served by sph_retina_amd")
+    return _sph2pob_iou_auxiliary(bboxes1, bboxes2, 'naive', 'iou', is_aligned, 'common', 'arc', 'equator')
+
+
 def sph2pob_legacy_iou(bboxes1, bboxes2, mode='iou', is_aligned=False, calculator='common', rbb_edge='arc'):
     return _sph2pob_iou_auxiliary(bboxes1, bboxes2, 'legacy', mode, is_aligned, calculator, rbb_edge, None)
 

@@ -7,12 +7,14 @@
 import torch
 
 from ..registry import IOU_CALCULATORS
-from .sph_iou_api import fov_iou, sph2pob_efficient_iou, sph2pob_legacy_iou, sph2pob_standard_iou, sph_iou
+from .sph_iou_api import (fov_iou, naive_iou, sph2pob_efficient_iou, sph2pob_legacy_iou, sph2pob_standard_iou, sph_iou,
+                          unbiased_iou)
 
 _ALL_BACKENDS = ['unbiased_iou', 'sph2pob_standard_iou', 'sph2pob_legacy_iou', 'sph2pob_efficient_iou', 'naive_iou',
                  'fov_iou', 'sph_iou', 'kent_iou']
 _HIP_BACKENDS = {'sph2pob_standard_iou': sph2pob_standard_iou, 'sph2pob_legacy_iou': sph2pob_legacy_iou,
-                 'sph2pob_efficient_iou': sph2pob_efficient_iou, 'sph_iou': sph_iou, 'fov_iou': fov_iou}
+                 'sph2pob_efficient_iou': sph2pob_efficient_iou, 'sph_iou': sph_iou, 'fov_iou': fov_iou,
+                 'unbiased_iou': unbiased_iou, 'naive_iou': naive_iou}
 
 
 @IOU_CALCULATORS.register_module()
@@ -46,6 +48,6 @@ def sph_overlaps(bboxes1, bboxes2, mode='iou', is_aligned=False, backend='unbias
     fn = _HIP_BACKENDS.get(backend)
     if fn is None:
         raise NotImplementedError(
-            f"backend '{backend}' is not on the Sph2Pob hot path served by sph_retina_amd (SURVEY.md §8f-4); "
+            f"backend '{backend}' (Kent distributions) is outside the Sph2Pob hot path served by sph_retina_amd; "
             "use one of " + ', '.join(sorted(_HIP_BACKENDS)))
     return fn(bboxes1, bboxes2, mode, is_aligned)

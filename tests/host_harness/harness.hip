@@ -5,6 +5,7 @@
 #include "../../sph_retina_amd/csrc/sph2pob_device.hpp"
 #include "../../sph_retina_amd/csrc/sph2pob_loss.hpp"
 #include "../../sph_retina_amd/csrc/sph2pob_fast.hpp"
+#include "../../sph_retina_amd/csrc/sph2pob_unbiased.hpp"
 
 using namespace sph2pob;
 
@@ -50,6 +51,14 @@ static void tbwd_loop(const float* b1, const float* b2, const float* g1, const f
     }
 }
 
+template <int DIM>
+static void extra_loop(const float* b1, const float* b2, int64_t n, int which, float* out) {
+    for (int64_t i = 0; i < n; i++) {
+        float x[5] = {0, 0, 0, 0, 0}, y[5] = {0, 0, 0, 0, 0};
+        for (int k = 0; k < DIM; k++) { x[k] = b1[i * DIM + k]; y[k] = b2[i * DIM + k]; }
+        out[i] = which == 0 ? unbiased_pair_iou<DIM, false>(x, y) : which == 1 ? unbiased_pair_iou<DIM, true>(x, y) : naive_iou<DIM>(x, y);
+    }
+}
 extern "C" {
 int harness_transform_bwd(const float* b1, const float* b2, const float* g1, const float* g2, int64_t n, int dim,
                           int variant, int edge, int jitter, float* o1, float* o2) {
@@ -73,6 +82,11 @@ int harness_iou(const float* b1, const float* b2, int64_t n, int dim, int varian
     if (variant == 0) { if (dim == 4) iou_loop<0, 4>(b1, b2, n, mode, edge, angle, out); else iou_loop<0, 5>(b1, b2, n, mode, edge, angle, out); }
     else if (variant == 1) { if (dim == 4) iou_loop<1, 4>(b1, b2, n, mode, edge, angle, out); else iou_loop<1, 5>(b1, b2, n, mode, edge, angle, out); }
     else iou_loop<2, 4>(b1, b2, n, mode, edge, angle, out);
+    return 0;
+}
+// which: 0 = unbiased IoU (double), 1 = unbiased IoU with the reference's fp32 roundings, 2 = naive IoU
+int harness_extra_iou(const float* b1, const float* b2, int64_t n, int dim, int which, float* out) {
+    if (dim == 4) extra_loop<4>(b1, b2, n, which, out); else extra_loop<5>(b1, b2, n, which, out);
     return 0;
 }
 int harness_planar_iou(const float* p1, const float* p2, int64_t n, int mode, float* out) {

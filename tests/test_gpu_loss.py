@@ -189,3 +189,28 @@ def test_diff_calculator_is_autograd_capable(L):
     ref = g['gpred_iou']
     d = np.abs(p.grad.cpu().numpy() - ref)
     assert np.median(d) < 1e-6 * np.abs(ref).max() and d.max() < 5e-3 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('wdim', [1, 4])
+def test_sparse_weights_dense_head_pattern(L, oracle, wdim):
+    """RetinaNet passes every anchor with weight 0 on the negatives (sph_retina_head.py:261-264): waves whose weights
+    are all zero are skipped by the kernels — results must equal the dense computation times the weights."""
+    n = 70001
+    t = oracle.generate_boxes(n, 5, box='bfov', alpha=(5, 60), beta=(5, 60))
+    p = t + np.random.default_rng(1).normal(0, 3, t.shape).astype(np.float32)
+    p[:, 1] = np.clip(p[:, 1], 1, 179)
+    p[:, 2:] = np.clip(p[:, 2:], 2, 100)
+    w = np.zeros((n, wdim), np.float32)
+    w[np.random.default_rng(2).integers(0, n, 150)] = 1.0   # isolated positives
+    w[5000:5300] = 0.5                                        # a run of positives spanning several waves
+    Ln = L.Sph2PobIoULoss(mode='ciou', reduction='none')
+    pd = cu(p, True)
+    dense = Ln(pd, cu(t))
+    dense.backward(cu(w.mean(1) if wdim > 1 else w[:, 0]))
+    ps = cu(p, True)
+    sparse = Ln(ps, cu(t), cu(w) if wdim > 1 else cu(w[:, 0]))
+    sparse.sum().backward()
+    wv = cu(w.mean(1) if wdim > 1 else w[:, 0])
+    assert torch.equal(sparse, dense.detach() * wv)
+    assert torch.equal(ps.grad, pd.grad)
+    assert float(ps.grad[w.reshape(n, -1).sum(1) == 0].abs().max()) == 0.0

@@ -80,8 +80,8 @@ def test_single_class_op_and_edge_cases(N, oracle):
     assert keep.tolist() == [int(np.argmax(s[:130]))]
     with pytest.raises(ValueError):
         N.SphNMS()(cu(b), cu(s), cu(np.zeros(700, np.int64)), None)
-    with pytest.raises(NotImplementedError):
-        N.SphNMS('unbiased_iou')
+    with pytest.raises(TypeError):
+        N.SphNMS('planar_iou')
 
 
 def test_multiclass_nms_wrapper(N, oracle):

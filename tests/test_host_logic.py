@@ -36,8 +36,8 @@ def test_option_assertions_match_reference():
         S.sph_overlaps(a, b, backend='xinyuan')
     with pytest.raises(AssertionError):
         S.SphOverlaps2D(backend='sph2pob_standard_iou')(torch.rand(3, 7), b)
-    with pytest.raises(NotImplementedError):  # backends outside the Sph2Pob hot path
-        S.sph_overlaps(a, b, backend='unbiased_iou')
+    with pytest.raises(NotImplementedError):  # Kent backends are outside the hot path
+        S.sph_overlaps(a, b, backend='kent_iou')
     with pytest.raises(AssertionError):
         S.Sph2PobIoULoss(mode='linear')       # sph2pob_iou_loss.py:19
     with pytest.raises(TypeError):

@@ -161,6 +161,38 @@ def coder(n=1_000_000):
     return out
 
 
+def unbiased(n=1_000_000):
+    """§8f-4: Unbiased IoU (fp64 spherical-polygon area) on the benchmark's uniform pairs, aligned; plus the CPU
+    restatement timed on a bounded sample for scale (README quotes 46 s per 1 M pairs for the reference's numpy)."""
+    from sph_retina_amd.iou import naive_iou, unbiased_iou
+    out = {'config': 'unbiased_iou / naive_iou, %d aligned pairs' % n}
+    for dim in (4, 5):
+        a, b = boxes(n, 0, dim), boxes(n, 1, dim)
+        near = a + torch.randn_like(a) * 4
+        near[:, 1].clamp_(1, 179)
+        near[:, 2:4].clamp_(1, 170)
+        tu = timeit(lambda: unbiased_iou(a, b, is_aligned=True), reps=20)
+        tn = timeit(lambda: unbiased_iou(a, near, is_aligned=True), reps=20)
+        tv = timeit(lambda: naive_iou(a, b, is_aligned=True), reps=50)
+        out['dim%d' % dim] = {'unbiased_uniform_us': tu * 1e6, 'unbiased_uniform_pairs_per_s': n / tu,
+                              'unbiased_nearby_us': tn * 1e6, 'unbiased_nearby_pairs_per_s': n / tn,
+                              'naive_uniform_us': tv * 1e6}
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from oracle import oracle as O
+        m = 200_000
+        a, b = boxes(m, 0, 4).cpu().numpy(), boxes(m, 1, 4).cpu().numpy()
+        O.unbiased_iou(a[:1000], b[:1000])
+        t0 = time.perf_counter()
+        O.unbiased_iou(a, b)
+        dt = time.perf_counter() - t0
+        out['cpu_restatement_pairs_per_s'] = m / dt
+        out['cpu_threads'] = O.max_threads()
+    except Exception as e:  # the oracle is test infrastructure; its absence must not break the GPU numbers
+        out['cpu_restatement_error'] = repr(e)
+    return out
+
+
 if __name__ == '__main__':
-    for fn in (config3, config4, coder):
+    for fn in (config3, config4, coder, unbiased):
         print(json.dumps(fn()), flush=True)
