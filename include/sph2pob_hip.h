@@ -190,6 +190,23 @@ int sph2pob_coder_decode_bwd_f32(const float* rois, const float* deltas, const f
                                  int num_classes, int box_dim, float max_ratio, int flags, float ctr_clamp,
                                  void* stream);
 
+/* ---- OBB L1 loss body: Sph2PobL1Loss after the Sph2Pob transform ----------------------------------
+ * Replaces sphdet/losses/sph2pob_l1_loss.py:28-88 on PLANAR boxes (x, y, w, h, a[rad]) as produced by
+ * sph2pob_transform_f32(..., jitter=1):  loss[i,k] = scale * weight[i,k] * |d[i,k]| with
+ *   ENCODE: d = bbox2delta(proposals, gt) = ((gx-px)/pw, (gy-py)/ph, log(gw/pw), log(gh/ph), (wrap(ga)-wrap(pa))/pi),
+ *           widths clipped at 1e-7; proposals = pred, gt = target (SWAP: the other way round, :31-32);
+ *           MODULUS: wrap(a) = (a + pi) mod pi (:84-88); the reference then takes L1 against zeros (:34);
+ *   otherwise d = pred - target.
+ * weight: (n,5) or NULL.  The backward gives the gradients w.r.t. both planar boxes (feed them to
+ * sph2pob_transform_bwd_f32 to reach the spherical boxes).  grad_target may be NULL.
+ */
+enum { SPH2POB_L1_ENCODE = 1, SPH2POB_L1_SWAP = 2, SPH2POB_L1_MODULUS = 4 };
+int sph2pob_obb_l1_fwd_f32(const float* planar_pred, const float* planar_target, const float* weight, float scale,
+                           float* loss, int64_t n, int flags, void* stream);
+int sph2pob_obb_l1_bwd_f32(const float* planar_pred, const float* planar_target, const float* weight,
+                           const float* grad_loss, float scale, float* grad_pred, float* grad_target, int64_t n,
+                           int flags, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

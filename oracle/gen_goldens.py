@@ -298,8 +298,42 @@ def unbiased_only():
     save('unbiased', **arrs)
 
 
+def l1_only():
+    """Sph2PobL1Loss fixtures (sphdet/losses/sph2pob_l1_loss.py:9-88 on the vendored mmdet L1Loss): the object is built
+    without its constructor (which stops in pdb.set_trace(), :24) and its real, decorator-wrapped forward is run."""
+    import torch.nn as nn
+    torch.manual_seed(20231028)
+    cls = R.l1_loss.Sph2PobL1Loss
+
+    def make(encode, swap, modifier, reduction='mean', loss_weight=1.0):
+        o = cls.__new__(cls)
+        nn.Module.__init__(o)
+        o.reduction, o.loss_weight, o.encode, o.swap, o.angle_modifier = reduction, loss_weight, encode, swap, modifier
+        return o
+    arrs = {}
+    for box in ('bfov', 'rbfov'):
+        t, p = gen(700, box=box, near=True)
+        w = torch.rand(700, t.shape[1])
+        w[::5] = 0
+        gout = torch.randn(700, 5)
+        arrs.update({box + '_pred': p, box + '_target': t, box + '_weight': w, box + '_gout': gout})
+        for name, cfg in (('enc', (True, False, 'original')), ('swapmod', (True, True, 'modulus')), ('raw', (False, False, 'original'))):
+            o = make(*cfg)
+            pr, tr = p.clone().requires_grad_(True), t.clone().requires_grad_(True)
+            el = o(pr, tr, reduction_override='none')
+            (el * gout).sum().backward()
+            k = f'{box}_{name}_'
+            arrs.update({k + 'elements': el.detach(), k + 'gpred': pr.grad, k + 'gtarget': tr.grad,
+                         k + 'elements64': f64(lambda a, b: o(a, b, reduction_override='none'), p, t),
+                         k + 'mean': o(p, t), k + 'mean_w_avg': make(*cfg, loss_weight=2.0)(p, t, w, avg_factor=97.0),
+                         k + 'sum_w': o(p, t, w, reduction_override='sum')})
+    save('l1', **arrs)
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'unbiased':
+    if len(sys.argv) > 1 and sys.argv[1] == 'l1':
+        l1_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'unbiased':
         unbiased_only()
     elif len(sys.argv) > 1 and sys.argv[1] == 'approx':
         approx_only()
@@ -310,3 +344,4 @@ if __name__ == '__main__':
         approx_only()
         coder_only()
         unbiased_only()
+        l1_only()

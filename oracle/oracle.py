@@ -430,3 +430,25 @@ def naive_iou(b1, b2, is_aligned=True, planar='mmcv'):
         rb = np.concatenate([pb, -(b[:, 4:5] * f(np.pi / 180))], axis=1).astype(f)
         out = planar_iou(ra, rb, mode='iou', planar=planar)
     return out if is_aligned else out.reshape(m, n)
+
+
+# ---- Sph2PobL1Loss -----------------------------------------------------------------------------------
+def obb_l1_elements(pred, target, encode=True, swap=False, angle_modifier='original', dtype=np.float32):
+    """Unweighted (n, 5) element losses of Sph2PobL1Loss — sphdet/losses/sph2pob_l1_loss.py:28-88 behind
+    Sph2PobTransfrom (sph2pob_transform.py:24-35): |bbox2delta(planar pred, planar target)| (or the swapped roles),
+    |planar pred - planar target| when encode=False."""
+    p, t = transform(pred, target, variant='standard', jitter=True, dtype=dtype)
+    p, t = p.astype(dtype), t.astype(dtype)
+    if not encode:
+        return np.abs(p - t)
+    pr, gt = (t, p) if swap else (p, t)
+    eps = dtype(1e-7)
+    pw, ph = np.maximum(pr[:, 2], eps), np.maximum(pr[:, 3], eps)
+    gw, gh = np.maximum(gt[:, 2], eps), np.maximum(gt[:, 3], eps)
+    pi = dtype(np.pi)
+
+    def wrap(a):
+        return a if angle_modifier == 'original' else np.mod(a + pi, pi)
+    d = np.stack([(gt[:, 0] - pr[:, 0]) / pw, (gt[:, 1] - pr[:, 1]) / ph, np.log(gw / pw), np.log(gh / ph),
+                  (wrap(gt[:, 4]) - wrap(pr[:, 4])) / pi], axis=-1)
+    return np.abs(d).astype(dtype)

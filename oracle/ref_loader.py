@@ -115,8 +115,9 @@ def load_reference():
     lutils = _load('mmdet.models.losses.utils', 'mmdet/models/losses/utils.py')
     ml = types.ModuleType('mmdet.models.losses')
     ml.weighted_loss = lutils.weighted_loss
-    ml.L1Loss = object
     sys.modules['mmdet.models.losses'] = ml
+    ml.__path__ = [os.path.join(REF, 'mmdet', 'models', 'losses')]
+    ml.L1Loss = _load('mmdet.models.losses.smooth_l1_loss', 'mmdet/models/losses/smooth_l1_loss.py').L1Loss
     rl = types.ModuleType('mmrotate.models.losses')
     import torch.nn as nn
     rl.RotatedIoULoss = nn.Module
@@ -125,6 +126,7 @@ def load_reference():
     sys.modules['mmrotate.models.losses'] = rl
     tr = _load('sphdet.losses.sph2pob_transform', 'sphdet/losses/sph2pob_transform.py')
     il = _load('sphdet.losses.sph2pob_iou_loss', 'sphdet/losses/sph2pob_iou_loss.py')
+    l1 = _load('sphdet.losses.sph2pob_l1_loss', 'sphdet/losses/sph2pob_l1_loss.py')
     nms = _load('sphdet.bbox.nms.sph_nms', 'sphdet/bbox/nms/sph_nms.py')
     gen = _load('ref_tests_generate_data', 'tests/utils/generate_data.py')
     # box coders: the vendored mmdet base class + a no-op registry
@@ -140,6 +142,6 @@ def load_reference():
 
     ns = types.SimpleNamespace(
         api=api, std=std, eff=eff, leg=leg, diff=diff, box_formator=box_formator, transform=tr, iou_loss=il,
-        nms=nms, gen=gen, loss_utils=lutils, coder4=coder4, coder5=coder5)
+        nms=nms, gen=gen, loss_utils=lutils, coder4=coder4, coder5=coder5, l1_loss=l1)
     _CACHE['ns'] = ns
     return ns

@@ -56,6 +56,9 @@ SIGNATURES = {
                                  ctypes.c_float, _int, ctypes.c_float, ctypes.c_void_p],
     'sph2pob_coder_decode_bwd_f32': [_c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p, ctypes.c_void_p, _c_f32p, _i64, _int,
                                      _int, ctypes.c_float, _int, ctypes.c_float, ctypes.c_void_p],
+    'sph2pob_obb_l1_fwd_f32': [_c_f32p, _c_f32p, _c_f32p, ctypes.c_float, _c_f32p, _i64, _int, ctypes.c_void_p],
+    'sph2pob_obb_l1_bwd_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_float, _c_f32p, _c_f32p, _i64, _int,
+                               ctypes.c_void_p],
 }
 _RESTYPES = {'sph2pob_target_arch': ctypes.c_char_p, 'sph2pob_error_string': ctypes.c_char_p,
              'sph2pob_nms_workspace_bytes': ctypes.c_int64, 'sph2pob_assign_workspace_bytes': ctypes.c_int64}

@@ -163,6 +163,88 @@ __global__ __launch_bounds__(kBlock) void coder_decode_bwd_kernel(const float* _
     store_row<DIM>(grad_deltas, i, g);
 }
 
+
+// ---- OBB L1 loss body on planar boxes (sphdet/losses/sph2pob_l1_loss.py:28-88) ----
+constexpr float kPiF = 3.14159265358979323846f;
+__device__ __forceinline__ float wrap_angle(float a, bool modulus) {
+    if (!modulus) return a;
+    float r = fmodf(a + kPiF, kPiF);  // torch `%` is a floored remainder: result takes the sign of the divisor
+    return (r != 0.0f && r < 0.0f) ? r + kPiF : r;
+}
+__device__ __forceinline__ float sgn(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+
+// deltas of proposals p w.r.t. gt g (bbox2delta :39-80, means 0 / stds 1)
+__device__ __forceinline__ void obb_deltas(const float* p, const float* g, bool modulus, float* d, float& pw, float& ph,
+                                           float& gw, float& gh) {
+    pw = clamp_lo(p[2], kEps); ph = clamp_lo(p[3], kEps);
+    gw = clamp_lo(g[2], kEps); gh = clamp_lo(g[3], kEps);
+    d[0] = (g[0] - p[0]) / pw;
+    d[1] = (g[1] - p[1]) / ph;
+    d[4] = (wrap_angle(g[4], modulus) - wrap_angle(p[4], modulus)) / kPiF;
+    d[2] = logf(gw / pw);
+    d[3] = logf(gh / ph);
+}
+
+__global__ __launch_bounds__(kBlock) void obb_l1_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                           const float* __restrict__ weight, float scale,
+                                                           float* __restrict__ loss, int64_t n, int flags) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float a[5], b[5], d[5], w[5] = {1.0f, 1.0f, 1.0f, 1.0f, 1.0f};
+    load_row<5>(pred, i, a);
+    load_row<5>(target, i, b);
+    if (weight) load_row<5>(weight, i, w);
+    if (flags & SPH2POB_L1_ENCODE) {
+        float pw, ph, gw, gh;
+        const bool swap = flags & SPH2POB_L1_SWAP;
+        obb_deltas(swap ? b : a, swap ? a : b, flags & SPH2POB_L1_MODULUS, d, pw, ph, gw, gh);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 5; k++) d[k] = a[k] - b[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) d[k] = scale * (fabsf(d[k]) * w[k]);
+    store_row<5>(loss, i, d);
+}
+
+__global__ __launch_bounds__(kBlock) void obb_l1_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                           const float* __restrict__ weight,
+                                                           const float* __restrict__ grad_loss, float scale,
+                                                           float* __restrict__ grad_pred, float* __restrict__ grad_target,
+                                                           int64_t n, int flags) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float a[5], b[5], d[5], u[5], w[5] = {1.0f, 1.0f, 1.0f, 1.0f, 1.0f}, ga[5], gb[5];
+    load_row<5>(pred, i, a);
+    load_row<5>(target, i, b);
+    load_row<5>(grad_loss, i, u);
+    if (weight) load_row<5>(weight, i, w);
+    if (flags & SPH2POB_L1_ENCODE) {
+        const bool swap = flags & SPH2POB_L1_SWAP;
+        const float* p = swap ? b : a;
+        const float* g = swap ? a : b;
+        float pw, ph, gw, gh, gp[5], gg[5];
+        obb_deltas(p, g, flags & SPH2POB_L1_MODULUS, d, pw, ph, gw, gh);
+#pragma unroll
+        for (int k = 0; k < 5; k++) u[k] = (u[k] * scale) * w[k] * sgn(d[k]);
+        gg[0] = u[0] / pw; gp[0] = -gg[0];
+        gg[1] = u[1] / ph; gp[1] = -gg[1];
+        // clip(min=eps) passes gradients where the width is >= eps
+        gp[2] = p[2] >= kEps ? -(u[0] * (g[0] - p[0]) / pw) / pw - u[2] / pw : 0.0f;
+        gp[3] = p[3] >= kEps ? -(u[1] * (g[1] - p[1]) / ph) / ph - u[3] / ph : 0.0f;
+        gg[2] = g[2] >= kEps ? u[2] / gw : 0.0f;
+        gg[3] = g[3] >= kEps ? u[3] / gh : 0.0f;
+        gg[4] = u[4] / kPiF; gp[4] = -gg[4];
+#pragma unroll
+        for (int k = 0; k < 5; k++) { ga[k] = swap ? gg[k] : gp[k]; gb[k] = swap ? gp[k] : gg[k]; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 5; k++) { ga[k] = (u[k] * scale) * w[k] * sgn(a[k] - b[k]); gb[k] = -ga[k]; }
+    }
+    store_row<5>(grad_pred, i, ga);
+    if (grad_target) store_row<5>(grad_target, i, gb);
+}
+
 Norm make_norm(const float* means, const float* stds, int dim) {
     Norm nm;
     for (int k = 0; k < 5; k++) {
@@ -230,6 +312,29 @@ int sph2pob_coder_decode_bwd_f32(const float* rois, const float* deltas, const f
         hipLaunchKernelGGL((coder_decode_bwd_kernel<4>), grid, dim3(kBlock), 0, (hipStream_t)stream, rois, deltas, grad_boxes, nm, grad_deltas, total, num_classes, max_ratio, flags, ctr_clamp);
     else
         hipLaunchKernelGGL((coder_decode_bwd_kernel<5>), grid, dim3(kBlock), 0, (hipStream_t)stream, rois, deltas, grad_boxes, nm, grad_deltas, total, num_classes, max_ratio, flags, ctr_clamp);
+    return status();
+}
+
+int sph2pob_obb_l1_fwd_f32(const float* planar_pred, const float* planar_target, const float* weight, float scale,
+                           float* loss, int64_t n, int flags, void* stream) {
+    if (flags & ~7) return SPH2POB_ERR_OPTION;
+    if (n < 0 || n > kMaxElems) return SPH2POB_ERR_SIZE;
+    if (n == 0) return 0;
+    if (!planar_pred || !planar_target || !loss) return SPH2POB_ERR_NULL;
+    dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(obb_l1_fwd_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, planar_pred, planar_target, weight, scale, loss, n, flags);
+    return status();
+}
+
+int sph2pob_obb_l1_bwd_f32(const float* planar_pred, const float* planar_target, const float* weight,
+                           const float* grad_loss, float scale, float* grad_pred, float* grad_target, int64_t n,
+                           int flags, void* stream) {
+    if (flags & ~7) return SPH2POB_ERR_OPTION;
+    if (n < 0 || n > kMaxElems) return SPH2POB_ERR_SIZE;
+    if (n == 0) return 0;
+    if (!planar_pred || !planar_target || !grad_loss || !grad_pred) return SPH2POB_ERR_NULL;
+    dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(obb_l1_bwd_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, planar_pred, planar_target, weight, grad_loss, scale, grad_pred, grad_target, n, flags);
     return status();
 }
 
