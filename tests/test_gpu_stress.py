@@ -54,3 +54,44 @@ def test_loss_adversarial_sets_finite():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
     import stress_loss
     assert stress_loss.run() == 0
+
+
+def test_launchers_are_graph_capturable():
+    """The C ABI only enqueues on the given stream (no allocation, no synchronisation): a step made of the IoU kernel,
+    the fused loss forward + backward and the coder decode replays from a hipGraph with identical results."""
+    import torch
+    import sph_retina_amd as S
+    from oracle import oracle as O
+    n = 50000
+    b1 = torch.from_numpy(O.generate_boxes(n, 3)).cuda()
+    b2 = torch.from_numpy(O.generate_boxes(n, 4)).cuda()
+    anchors = b1.clone()
+    deltas = (torch.randn(n, 4, device='cuda') * 0.1).requires_grad_(True)
+    coder = S.DeltaXYWHSphBBoxCoder(target_stds=(0.1, 0.1, 0.2, 0.2))
+    loss_fn = S.Sph2PobIoULoss(mode='ciou')
+
+    def step():
+        iou = S.sph2pob_standard_iou(b1, b2, is_aligned=True)
+        loss = loss_fn(coder.decode(anchors, deltas), b1)
+        grad, = torch.autograd.grad(loss, deltas)
+        return iou, loss.detach(), grad   # keeping the autograd graph alive across iterations breaks torch's capture
+    eager = [t.clone() for t in step()]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):                       # warm-up on the capture stream (workspace allocation, lazy init)
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = step()
+    for t in captured:
+        t.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(eager, captured):
+        assert torch.equal(a, b)
+    b2.copy_(b1)                                 # new inputs, same graph
+    graph.replay()
+    torch.cuda.synchronize()
+    assert float(captured[0].min()) > 0.99
