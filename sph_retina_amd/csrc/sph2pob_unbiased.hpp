@@ -112,12 +112,15 @@ SPH_DEV void ub_box(const float (&rad)[5], UbBox& B) {
         B.n[2] = ub_roll<R, true>(m, B.n[2]);
         B.n[3] = ub_roll<R, true>(m, B.n[3]);
     }
-    B.corner = ub_acos_clip(-ddot(B.n[0], B.n[2]));
-    if (R) {  // area :10-12 in float32
+    if (R) {  // area :10-12 in float32; corner angle from the (partly float32) normals as interArea does
+        B.corner = ub_acos_clip(-ddot(B.n[0], B.n[2]));
         const float s = -sinf(rad[2] / 2) * sinf(rad[3] / 2);
         B.area = (double)(4 * acosf(s) - (float)(2 * 3.141592653589793));
     } else {
-        B.area = 4.0 * acos(-sa * sb) - 2.0 * 3.141592653589793;
+        // N_left . N_up = sin(a/2) sin(b/2) (the rotation preserves it): one acos serves the four corner angles and
+        // the area 4 acos(-sin sin) - 2 pi; the dot product of the rounded normals differs from it by ~1e-16
+        B.corner = acos(-sa * sb);
+        B.area = 4.0 * B.corner - 2.0 * 3.141592653589793;
     }
     // circumradius for the disjointness cull: corners sit at (+-tan a2, +-tan b2, 1) in the box frame
     if (ca > 0.02 && cb > 0.02) {
@@ -136,6 +139,16 @@ SPH_DEV void ub_minmax(const DVec& t, const DVec& n, double& lo, double& hi) {
     const double d = ddot(t, n);
     lo = fmin(lo, d);   // fmin/fmax drop NaN: handled by the caller through nrm
     hi = fmax(hi, d);
+}
+
+// np.round(d / (|t| + off), 8) >= 0 for the smallest (most negative) dot product d = lo <= 0 of a candidate, i.e.
+// lo * 1e8 >= -0.5 * (sqrt(tt) + off).  |t| <= ~1 (cross product of unit normals), so the square root is only needed
+// inside the 5e-9 band where the reference's rounding decides; NaN (tt != tt) is never inside.
+SPH_DEV bool ub_inside(double lo, double tt, double off) {
+    if (!(tt == tt)) return false;
+    if (lo >= 0.0) return true;
+    if (lo * 1e8 < -0.51) return false;
+    return lo * 1e8 >= -0.5 * (sqrt(tt) + off);
 }
 
 template <int DIM, bool R>
@@ -166,14 +179,14 @@ SPH_DEV float unbiased_pair_iou(const float (&in1)[5], const float (&in2)[5]) {
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const DVec t = dcross(P.n[ea[c]], P.n[eb[c]]);
-                const double nrm = sqrt(ddot(t, t));           // corners: no 1e-10 (getNormal :41-43)
+                const double tt = ddot(t, t);                  // corners: no 1e-10 (getNormal :41-43)
                 double lo = 0.0, hi = 0.0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     if (k != ea[c] && k != eb[c]) ub_minmax(t, P.n[k], lo, hi);
                     ub_minmax(t, Q.n[k], lo, hi);
                 }
-                if (nrm > 0.0 && lo * 1e8 >= -0.5 * nrm) {
+                if (tt > 0.0 && ub_inside(lo, tt, 0.0)) {
                     sum += P.corner;
                     count++;
                 }
@@ -185,14 +198,14 @@ SPH_DEV float unbiased_pair_iou(const float (&in1)[5], const float (&in2)[5]) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const DVec t = dcross(A.n[i], B.n[j]);
-                const double nrm = sqrt(ddot(t, t)) + 1e-10;
+                const double tt = ddot(t, t);
                 double lo = 0.0, hi = 0.0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     if (k != i) ub_minmax(t, A.n[k], lo, hi);
                     if (k != j) ub_minmax(t, B.n[k], lo, hi);
                 }
-                const bool in_p = lo * 1e8 >= -0.5 * nrm, in_q = hi * 1e8 <= 0.5 * nrm;
+                const bool in_p = ub_inside(lo, tt, 1e-10), in_q = ub_inside(-hi, tt, 1e-10);
                 if (in_p || in_q) {
                     const double ang = ub_acos_clip(-ddot(A.n[i], B.n[j]));
                     const int c = (in_p ? 1 : 0) + (in_q ? 1 : 0);

@@ -204,3 +204,33 @@ def test_gpu_unbiased_full_size_properties(oracle):
     sample = slice(0, 20000)
     k = oracle.unbiased_iou(b1[sample], b2[sample], prec='kernel')
     assert (np.abs(u[sample].cpu().numpy() - k) > 1e-6).sum() <= 2
+
+
+# README "Comprehensive Comparison", column R_all: Pearson correlation with Unbiased-IoU over uniform pairs with
+# alpha, beta in [1, 100) (protocol: tests/test_all_ious.py:29-88, :225-241; 10 k pairs there).
+README_R_ALL = {'sph_iou': 0.7819, 'fov_iou': 0.9600, 'standard': 0.9989}
+
+
+def test_readme_consistency_table_with_restatements(oracle):
+    n = 30000
+    b1, b2 = oracle.generate_boxes(n, 0), oracle.generate_boxes(n, 1)
+    u = oracle.unbiased_iou(b1, b2, prec='kernel').astype(np.float64)
+    for variant, published in README_R_ALL.items():
+        r = np.corrcoef(oracle.iou_aligned(b1, b2, variant=variant).astype(np.float64), u)[0, 1]
+        tol = 0.0006 if variant == 'standard' else 0.02      # sampling spread of R at 10 k pairs for the loose methods
+        assert abs(r - published) < tol, (variant, r, published)
+
+
+@pytest.mark.gpu
+def test_gpu_readme_consistency_table_at_full_size(oracle):
+    import sph_retina_amd.iou as I
+    n = 1_000_000
+    t1, t2 = cu(oracle.generate_boxes(n, 0)), cu(oracle.generate_boxes(n, 1))
+    u = I.unbiased_iou(t1, t2, is_aligned=True).double()
+    got = {}
+    for variant, fn in (('sph_iou', I.sph_iou), ('fov_iou', I.fov_iou), ('standard', I.sph2pob_standard_iou),
+                        ('efficient', I.sph2pob_efficient_iou)):
+        got[variant] = torch.corrcoef(torch.stack([fn(t1, t2, is_aligned=True).double(), u]))[0, 1].item()
+    assert abs(got['standard'] - README_R_ALL['standard']) < 0.0004, got
+    assert abs(got['efficient'] - got['standard']) < 1e-5, got
+    assert abs(got['fov_iou'] - README_R_ALL['fov_iou']) < 0.01 and abs(got['sph_iou'] - README_R_ALL['sph_iou']) < 0.02, got
