@@ -14,6 +14,7 @@ namespace {
 using namespace sph2pob;
 
 constexpr int kBlock = 256;  // 4 waves of 64 lanes
+constexpr int kCUs = 256;    // MI355X: 8 XCDs x 32 CUs
 
 // tuning knobs (environment, read once): SPH2POB_NO_COMPACT=1 disables the compacting kernel,
 // SPH2POB_SLICES_PER_WAVE sets how many 64-pair slices each wave of the compacting kernel walks
@@ -21,6 +22,7 @@ static bool g_no_compact = getenv("SPH2POB_NO_COMPACT") != nullptr;
 static bool g_prefetch = getenv("SPH2POB_NO_PREFETCH") == nullptr;
 static int g_pw_rows = getenv("SPH2POB_PW_ROWS") ? atoi(getenv("SPH2POB_PW_ROWS")) : 0;
 static int g_slices_per_wave = getenv("SPH2POB_SLICES_PER_WAVE") ? atoi(getenv("SPH2POB_SLICES_PER_WAVE")) : 4;
+static int g_wgs_per_cu = getenv("SPH2POB_WGS_PER_CU") ? atoi(getenv("SPH2POB_WGS_PER_CU")) : 0;  // experiment knob
 
 template <int DIM>
 __device__ __forceinline__ void load_box(const float* __restrict__ p, int64_t i, float (&b)[5]) {
@@ -601,10 +603,18 @@ struct AlignedLaunch {
     template <int V, int D> int run() {
         dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
         if (fast && V < 2 && angle == SPH2POB_ANGLE_EQUATOR && n < ((int64_t)1 << 31) - 64 && !g_no_compact) {
-            // persistent-style grid: enough slices per wave for the survivor stacks to fill
+            // persistent-style grid.  Measured on MI355X (tools/sweep_slices.sh, profiles/r01h_sweep_wgs_per_cu.log):
+            // (i) every CU must hold the same number of workgroups — 1 303 workgroups (5.09 per CU) take 11.4 us
+            // for 1 M pairs, 1 536 (6 per CU) take 10.2 us; (ii) 6 per CU (24 waves per CU, LDS allows 7) is the
+            // best or within noise of the best from 125 k to 8 M pairs; (iii) small launches want one slice per wave
+            // rather than full survivor stacks.  Hence: whole multiples of the CU count, at most 6 per CU, at least
+            // one 64-pair slice per wave.
             int64_t slices = (n + 63) / 64;
-            int64_t wgs = (slices + 4 * g_slices_per_wave - 1) / (4 * g_slices_per_wave);
-            if (wgs > 256 * 7) wgs = 256 * 7;
+            int64_t wgs = (slices + 3) / 4;
+            if (g_slices_per_wave > 0 && getenv("SPH2POB_SLICES_PER_WAVE")) wgs = (slices + 4 * g_slices_per_wave - 1) / (4 * g_slices_per_wave);
+            else if (wgs > kCUs) { wgs = (wgs + kCUs - 1) / kCUs * kCUs; if (wgs > kCUs * 6) wgs = kCUs * 6; }
+            if (wgs > kCUs * 7) wgs = kCUs * 7;
+            if (g_wgs_per_cu > 0) wgs = kCUs * g_wgs_per_cu;
             if (wgs < 1) wgs = 1;
             if (g_prefetch)
                 hipLaunchKernelGGL((iou_aligned_compact_kernel<V >= 2 ? 0 : V, D, true>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge);

@@ -1,12 +1,17 @@
 #!/bin/bash
-# GPU box: dominant-kernel time (bench.py's HIP-event measurement) against SPH2POB_SLICES_PER_WAVE and batch size
+# GPU box: dominant-kernel time (bench.py's HIP-event measurement) against the number of workgroups per CU and batch size
+# usage: tools/sweep_slices.sh [sizes...]   (SPH2POB_WGS_PER_CU forces 256*k workgroups; default = the launcher's rule)
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
-for n in 1000000 4000000; do
-  for s in 1 2 3 4 6 8; do
-    SPH2POB_SLICES_PER_WAVE=$s python3 bench.py --steps 300 --warmup 20 --no-cpu-baseline --pairs $n | python3 -c "
+run() {
+  python3 bench.py --steps 400 --warmup 20 --no-cpu-baseline --pairs $1 | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('pairs', $n, 'slices', $s, 'ms_per_step %.5f' % d['ms_per_step'], 'frac %.3f' % d['roofline']['frac'])"
+print('pairs', $1, '$2', 'kernel_us %.3f' % (d['roofline']['kernel_ms']*1e3), 'frac %.3f' % d['roofline']['frac'])"
+}
+for n in ${@:-125000 250000 500000 750000 1000000 1500000 3000000 8000000}; do
+  run $n "default"
+  for k in 1 2 3 4 5 6 7; do
+    SPH2POB_WGS_PER_CU=$k run $n "wgs_per_cu=$k"
   done
 done
