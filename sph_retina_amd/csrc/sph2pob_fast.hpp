@@ -191,9 +191,28 @@ SPH_DEV bool cull_pair(const CullBox& g, const CullBox& p) {
     float C = g.c * p.c + (g.s * p.s) * hw_cos_rev(p.th_rev - g.th_rev);
     return (R < 3.0f) & (C < cosR_lb - 1e-4f);
 }
+// Aligned form of the same test with 4 quarter-rate instructions instead of 7 (a quarter-rate op costs 8 plain FMAs):
+//   cos(angular distance) = 1/2 [cos(phi_g - phi_p) (1 + cos dtheta) + cos(phi_g + phi_p) (1 - cos dtheta)]   (3 v_cos)
+//   (r_g + r_p)^2 = (d_g + d_p + 2 sqrt(d_g d_p)) / 4,  d = w^2 + h^2                                        (1 v_rsq)
+// and the 1.5e-3 rad margin moved into R^2: (R0 + m)^2 <= R0^2 + 3 m + m^2 for R0 < 3 (cos R's polynomial lower bound
+// decreases in R^2 on the whole range, so a larger R^2 only culls less).  A degenerate box (d = 0) gives 0 * inf = NaN
+// and is never culled, like the +inf radius of cull_box.
 template <int DIM>
-SPH_DEV bool fast_cull(const float (&in1)[5], const float (&in2)[5], int edge) {
-    return cull_pair(cull_box(in1, edge), cull_box(in2, edge));
+SPH_DEV bool fast_cull(const float (&g)[5], const float (&p)[5], int edge) {
+#pragma clang fp contract(fast)
+    float wg = fminf(g[2], 180.0f) * kDeg2Rad, hg = fminf(g[3], 180.0f) * kDeg2Rad;
+    float wp = fminf(p[2], 180.0f) * kDeg2Rad, hp = fminf(p[3], 180.0f) * kDeg2Rad;
+    if (edge != EDGE_ARC) { wg = edge_length(wg, edge); hg = edge_length(hg, edge); wp = edge_length(wp, edge); hp = edge_length(hp, edge); }
+    const float dg = wg * wg + hg * hg, dp = wp * wp + hp * hp, prod = dg * dp;
+    const float R2 = 0.25f * (dg + dp) + 0.5f * (prod * fast_rsq(prod)) + 9.01e-3f;
+    const float cosR_lb = fmaf(fmaf(fmaf(-1.0f / 720.0f, R2, 1.0f / 24.0f), R2, -0.5f), R2, 1.0f);
+    const float kRev = 1.0f / 360.0f;
+    const float phg = fminf(fmaxf(g[1], 0.0f), 180.0f), php = fminf(fmaxf(p[1], 0.0f), 180.0f);
+    const float thg = fminf(fmaxf(g[0], 0.0f), 360.0f), thp = fminf(fmaxf(p[0], 0.0f), 360.0f);
+    const float u = hw_cos_rev((phg - php) * kRev), v = hw_cos_rev((phg + php) * kRev);
+    const float cD = hw_cos_rev((thp - thg) * kRev);
+    const float C = 0.5f * ((u + v) + (u - v) * cD);
+    return (R2 < 8.9f) & (C < cosR_lb - 1e-4f);
 }
 
 // trig by-products of stage 1 that the loss adjoint reuses
