@@ -87,8 +87,8 @@ def pmc_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=5000)
+    ap.add_argument('--warmup', type=int, default=500)
     ap.add_argument('--pairs', type=int, default=PAIRS_PER_GPU, help='pairs per GPU per step')
     ap.add_argument('--variant', default=VARIANT, choices=['standard', 'efficient', 'legacy'])
     ap.add_argument('--arithmetic', default='fast', choices=['fast', 'reference'],
