@@ -15,7 +15,6 @@ import ctypes
 import torch
 import torch.nn as nn
 
-from .. import _lib
 from .. import _torch_glue as G
 from ..registry import LOSSES
 

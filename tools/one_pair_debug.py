@@ -1,5 +1,5 @@
 import os, sys
-import numpy as np, torch
+import torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import sph_retina_amd as S
 from sph_retina_amd.losses import Sph2PobIoULoss

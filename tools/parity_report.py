@@ -5,7 +5,7 @@ import sys
 import os
 
 import numpy as np
-import torch
+import torch  # noqa: F401  (initialises the HIP runtime before the product is imported)
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
