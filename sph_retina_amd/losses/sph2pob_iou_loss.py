@@ -126,3 +126,43 @@ class SphIoULoss(OBBIoULoss):
         assert iou_calculator in ['sph2pob_standard', 'sph2pob_standard_iou'], \
             "only the Sph2Pob calculator is on the MI355X hot path ('sph'/'fov' closed forms: SURVEY §8f-4)"
         super().__init__(mode=mode, eps=eps, reduction=reduction, loss_weight=loss_weight)
+
+
+@LOSSES.register_module()
+class SphIoULossLegacy(nn.Module):
+    """`@Sph2PobTransfrom() class SphIoULossLegacy(RotatedIoULoss)` (reference sph2pob_iou_loss.py:199-216): mmrotate
+    0.3.2's RotatedIoULoss — `-log(IoU)` ('log', default), `1 - IoU` ('linear') or `1 - IoU^2` ('square') of the
+    differentiable rotated IoU clamped at `eps` — on the Sph2Pob planar boxes.  The IoU and its gradient come from the
+    fused loss kernels (the `iou` mode, pinned by the reference-generated loss fixtures); the scalar post-map is three
+    element-wise torch ops.  mmrotate is absent here: its post-map is restated from the published source — parity of
+    that part is UNPINNED."""
+
+    def __init__(self, linear=False, eps=1e-6, reduction='mean', loss_weight=1.0, mode='log'):
+        super().__init__()
+        assert mode in ['linear', 'square', 'log']
+        self.mode = 'linear' if linear else mode
+        self.eps = eps
+        self.reduction = reduction
+        self.loss_weight = loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None, **kwargs):
+        assert reduction_override in (None, 'none', 'mean', 'sum')
+        reduction = reduction_override if reduction_override else self.reduction
+        if weight is not None and weight.dim() > 1:
+            if target.size(-1) == 4:   # Sph2PobTransfrom widens (n, 4) weights with their mean (sph2pob_transform.py:32-34)
+                weight = torch.cat([weight, weight.mean(-1, keepdim=True)], dim=-1)
+            weight = weight.mean(-1)
+        if weight is not None and not torch.any(weight > 0) and reduction != 'none':
+            return (pred * weight[:, None]).sum()
+        ious = 1.0 - sph2pob_iou_loss(pred, target, mode='iou', reduction='none')
+        ious = ious.clamp(min=self.eps)
+        loss = 1 - ious if self.mode == 'linear' else (1 - ious ** 2 if self.mode == 'square' else -ious.log())
+        if weight is not None:
+            loss = loss * weight
+        if avg_factor is None:
+            loss = loss.mean() if reduction == 'mean' else (loss.sum() if reduction == 'sum' else loss)
+        elif reduction == 'mean':
+            loss = loss.sum() / (avg_factor + _F32_EPS)
+        elif reduction != 'none':
+            raise ValueError('avg_factor can not be used with reduction="sum"')
+        return self.loss_weight * loss

@@ -214,3 +214,25 @@ def test_sparse_weights_dense_head_pattern(L, oracle, wdim):
     assert torch.equal(sparse, dense.detach() * wv)
     assert torch.equal(ps.grad, pd.grad)
     assert float(ps.grad[w.reshape(n, -1).sum(1) == 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('mode', ['log', 'linear', 'square'])
+def test_sph_iou_loss_legacy_postmaps(L, mode):
+    """SphIoULossLegacy = RotatedIoULoss post-map on the fused IoU (parity of the mmrotate post-map: unpinned)."""
+    from sph_retina_amd.losses import SphIoULossLegacy
+    g = load_golden('loss_rbfov')
+    pred, target = cu(g['pred'], True), cu(g['target'])
+    iou_ref = 1.0 - g['loss_iou'] if 'loss_iou' in g else None
+    loss = SphIoULossLegacy(mode=mode, reduction='none')(pred, target)
+    iou = (1.0 - L.Sph2PobIoULoss(mode='iou', reduction='none')(cu(g['pred']), target)).clamp(min=1e-6)
+    want = {'log': -iou.log(), 'linear': 1 - iou, 'square': 1 - iou ** 2}[mode]
+    assert torch.allclose(loss, want, rtol=1e-6, atol=1e-7)
+    loss.sum().backward()
+    assert torch.isfinite(pred.grad).all() and float(pred.grad.abs().max()) > 0
+    # chain rule against the fused IoU-mode gradient
+    p2 = cu(g['pred'], True)
+    L.Sph2PobIoULoss(mode='iou', reduction='none')(p2, target).backward(
+        {'log': 1.0 / iou, 'linear': torch.ones_like(iou), 'square': 2 * iou}[mode] * (iou > 1e-6))
+    assert torch.allclose(pred.grad, p2.grad, rtol=1e-4, atol=1e-7)
+    from sph_retina_amd.registry import build_loss
+    assert isinstance(build_loss(dict(type='SphIoULossLegacy')), SphIoULossLegacy)
