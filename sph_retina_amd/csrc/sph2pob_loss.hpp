@@ -122,6 +122,18 @@ SPH_DEV void loss_front_reference(const float (&b1)[5], const float (&b2)[5], Lo
 
 }  // namespace sph2pob
 #include "sph2pob_fast.hpp"
+
+namespace sph2pob {
+// 1 / b and a / b from the hardware reciprocal plus one Newton step (~1 ulp).  The IEEE divide expands to ~12
+// instructions, 5 of them at the slow issue rate (v_div_scale x2, v_div_fmas, v_div_fixup, v_rcp): the loss kernels
+// are VALU-issue-bound and divided 7 (forward) to 19 (backward) times per pair.  Only for denominators that cannot be
+// 0 / inf (sums with eps, squares of clamped extents); the clip reciprocals use the bare, clamped v_rcp.
+SPH_DEV float rcp_nr(float b) {
+    float r = fast_rcp(b);
+    return r * (2.0f - b * r);
+}
+SPH_DEV float fdiv(float a, float b) { return a * rcp_nr(b); }
+}  // namespace sph2pob
 namespace sph2pob {
 
 // closed-form front end (sph2pob_fast.hpp): same planar boxes, ~4x fewer instructions
@@ -162,9 +174,9 @@ SPH_DEV void planar_to_spherical_grads(const LossFront& f, PlanarGrad gP, Planar
     float Dp = -sg * sD;                 //  c_g . e_p
     float C = cg * cp + sg * sp * cD;    //  cos A
     float sin2 = N * N + D * D;          //  sin^2 A
-    float sinA = sqrtf(sin2);
-    float inv_s2 = sin2 > 1e-20f ? 1.0f / sin2 : 0.0f;
-    float inv_s = sin2 > 1e-20f ? 1.0f / sinA : 0.0f;
+    float inv_s = fast_rsq(sin2);
+    inv_s = sin2 > 1e-20f ? inv_s * (1.5f - 0.5f * sin2 * inv_s * inv_s) : 0.0f;  // 1 / sin A, one Newton step
+    float inv_s2 = inv_s * inv_s;
     // dA = -dC / sinA
     float dA_phg = -N * inv_s, dA_php = Np * inv_s;
     float dA_thg = -(sg * sp * sD) * inv_s, dA_thp = (sg * sp * sD) * inv_s;
@@ -234,7 +246,7 @@ SPH_DEV float pair_loss(const float (&pred)[5], const float (&target)[5], int lo
     // ---- planar IoU (value of mmcv diff_iou_rotated_2d: sphdet/iou/diff_iou_rotated.py:325-343) ----
     float c = ca * cb + sa * sb, s = sa * cb - ca * sb;
     // clamped reciprocals: exactly parallel edges (s == 0 after the jitter bumps) give finite, correctly ordered bounds
-    float ic = fminf(fmaxf(1.0f / c, -1e18f), 1e18f), is = fminf(fmaxf(1.0f / s, -1e18f), 1e18f);
+    float ic = fminf(fmaxf(fast_rcp(c), -1e18f), 1e18f), is = fminf(fmaxf(fast_rcp(s), -1e18f), 1e18f);
     float hwa = 0.5f * P.w, hha = 0.5f * P.h, hwb = 0.5f * T.w, hhb = 0.5f * T.h;
     float pax = -(dx * cb + dy * sb), pay = -(dy * cb - dx * sb);
     float pbx = dx * ca + dy * sa, pby = dy * ca - dx * sa;
@@ -243,7 +255,7 @@ SPH_DEV float pair_loss(const float (&pred)[5], const float (&target)[5], int lo
     float I = 0.5f * fmaxf(eA.area2 + eB.area2, 0.0f);
     float S1 = P.w * P.h, S2 = T.w * T.h;
     float U = S1 + S2 - I;
-    float iou_raw = I / U;
+    float iou_raw = fdiv(I, U);
     float iou = fminf(fmaxf(iou_raw, 0.0f), 1.0f);
     if (iou_out) *iou_out = iou;
 
@@ -264,18 +276,18 @@ SPH_DEV float pair_loss(const float (&pred)[5], const float (&target)[5], int lo
         ih = fmaxf(fminf(y2g, y2p) - fmaxf(y1g, y1p), 0.0f);
         ae = cw * ch;
         au = S1 + S2 - iw * ih;
-        pen_ratio = (ae - au) / (ae + eps);
+        pen_ratio = fdiv(ae - au, ae + eps);
         loss = 1.0f - (iou - fminf(fmaxf(pen_ratio, 0.0f), 1.0f));
     } else {
         c2 = cw * cw + ch * ch + eps;
         rho2 = dx * dx + dy * dy;
-        pen_ratio = rho2 / c2;
+        pen_ratio = fdiv(rho2, c2);
         float pen = fminf(fmaxf(pen_ratio, 0.0f), 1.0f);
         if (loss_mode == LOSS_CIOU) {
             const float factor = (float)(4.0 / (3.141592653589793 * 3.141592653589793));
-            dv = atanf(T.w / (T.h + eps)) - atanf(P.w / (P.h + eps));
+            dv = atan2_r(T.w, T.h + eps) - atan2_r(P.w, P.h + eps);   // widths and heights are positive
             v = factor * (dv * dv);
-            alpha = (iou > 0.5f ? 1.0f : 0.0f) * v / (1.0f - iou + v + eps);
+            alpha = fdiv((iou > 0.5f ? 1.0f : 0.0f) * v, 1.0f - iou + v + eps);
             pen = pen + alpha * v;
         }
         loss = 1.0f - (iou - pen);
@@ -286,7 +298,7 @@ SPH_DEV float pair_loss(const float (&pred)[5], const float (&target)[5], int lo
     PlanarGrad gP{0, 0, 0, 0}, gT{0, 0, 0, 0};
     // -- IoU term: L = 1 - iou  (torch.clamp passes gradient on the closed range [0, 1]) --
     if (iou_raw >= 0.0f && iou_raw <= 1.0f) {
-        float inv_u2 = 1.0f / (U * U);
+        float inv_u = rcp_nr(U), inv_u2 = inv_u * inv_u;
         float LI = -(S1 + S2) * inv_u2;  // dL/dI
         float LS = I * inv_u2;           // dL/dS1 = dL/dS2
         if (eA.area2 + eB.area2 <= 0.0f) LI = 0.0f;
@@ -309,7 +321,7 @@ SPH_DEV float pair_loss(const float (&pred)[5], const float (&target)[5], int lo
         if (loss_mode == LOSS_GIOU) {
             if (pen_ratio >= 0.0f && pen_ratio <= 1.0f) {
                 float den = ae + eps;
-                float Rae = (eps + au) / (den * den), Rau = -1.0f / den;
+                float iden = rcp_nr(den), Rae = (eps + au) * (iden * iden), Rau = -iden;
                 Lcw = Rae * ch; Lch = Rae * cw;
                 // au = S1 + S2 - iw*ih
                 gP.w += Rau * P.h; gP.h += Rau * P.w; gT.w += Rau * T.h; gT.h += Rau * T.w;
@@ -329,7 +341,7 @@ SPH_DEV float pair_loss(const float (&pred)[5], const float (&target)[5], int lo
             }
         } else {
             if (pen_ratio >= 0.0f && pen_ratio <= 1.0f) {
-                float Lrho = 1.0f / c2, Lc2 = -rho2 / (c2 * c2);
+                float Lrho = rcp_nr(c2), Lc2 = -rho2 * (Lrho * Lrho);
                 gT.x += Lrho * 2.0f * dx;
                 gP.x -= Lrho * 2.0f * dx;
                 Lcw = Lc2 * 2.0f * cw; Lch = Lc2 * 2.0f * ch;
@@ -338,7 +350,7 @@ SPH_DEV float pair_loss(const float (&pred)[5], const float (&target)[5], int lo
                 const float factor = (float)(4.0 / (3.141592653589793 * 3.141592653589793));
                 float Ldv = alpha * factor * 2.0f * dv;  // alpha is a constant (torch.no_grad) :188-189
                 float hpe = T.h + eps, hge = P.h + eps;
-                float qp = 1.0f / (hpe * hpe + T.w * T.w), qg = 1.0f / (hge * hge + P.w * P.w);
+                float qp = rcp_nr(hpe * hpe + T.w * T.w), qg = rcp_nr(hge * hge + P.w * P.w);
                 gT.w += Ldv * hpe * qp;  gT.h -= Ldv * T.w * qp;
                 gP.w -= Ldv * hge * qg;  gP.h += Ldv * P.w * qg;
             }
