@@ -298,6 +298,19 @@ def unbiased_only():
     save('unbiased', **arrs)
 
 
+def samples_backends_only():
+    """The reference's hard-coded sample pairs (tests/test_all_ious.py:244-261, geo2sph applied) through the other
+    backends its own test prints (:271-279): unbiased, Sph-IoU, FoV-IoU (naive needs mmcv.ops.bbox_overlaps: absent)."""
+    b1 = torch.tensor([[40, 50, 35, 55], [30, 60, 60, 60], [50, -78, 25, 46], [30, 75, 30, 60], [40, 70, 25, 30],
+                       [30, 75, 30, 30], [30, 60, 60, 60]]).float()
+    b2 = torch.tensor([[35, 20, 37, 50], [55, 40, 60, 60], [30, -75, 26, 45], [60, 40, 60, 60], [60, 85, 30, 30],
+                       [60, 55, 40, 50], [60, 60, 60, 60]]).float()
+    b1, b2 = R.box_formator.geo2sph(b1), R.box_formator.geo2sph(b2)
+    save('samples7_backends', b1=b1, b2=b2, unbiased=R.api.unbiased_iou(b1, b2, is_aligned=True),
+         unbiased64=f64(R.api.unbiased_iou, b1, b2, is_aligned=True), sph=R.api.sph_iou(b1, b2, is_aligned=True),
+         fov=R.api.fov_iou(b1, b2, is_aligned=True), unbiased_pw=R.api.unbiased_iou(b1, b2))
+
+
 def l1_only():
     """Sph2PobL1Loss fixtures (sphdet/losses/sph2pob_l1_loss.py:9-88 on the vendored mmdet L1Loss): the object is built
     without its constructor (which stops in pdb.set_trace(), :24) and its real, decorator-wrapped forward is run."""
@@ -331,7 +344,9 @@ def l1_only():
 
 
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'l1':
+    if len(sys.argv) > 1 and sys.argv[1] == 'samples_backends':
+        samples_backends_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'l1':
         l1_only()
     elif len(sys.argv) > 1 and sys.argv[1] == 'unbiased':
         unbiased_only()
@@ -345,3 +360,4 @@ if __name__ == '__main__':
         coder_only()
         unbiased_only()
         l1_only()
+        samples_backends_only()

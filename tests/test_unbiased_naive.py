@@ -234,3 +234,26 @@ def test_gpu_readme_consistency_table_at_full_size(oracle):
     assert abs(got['standard'] - README_R_ALL['standard']) < 0.0004, got
     assert abs(got['efficient'] - got['standard']) < 1e-5, got
     assert abs(got['fov_iou'] - README_R_ALL['fov_iou']) < 0.01 and abs(got['sph_iou'] - README_R_ALL['sph_iou']) < 0.02, got
+
+
+def test_reference_sample_pairs_other_backends(oracle):
+    """The 7 hard-coded pairs of the reference's tests/test_all_ious.py:244-261 through unbiased / Sph / FoV IoU."""
+    g = load_golden('samples7_backends')
+    b1, b2 = g['b1'], g['b2']
+    assert np.array_equal(oracle.unbiased_iou(b1, b2, prec='f64'), g['unbiased64'])
+    assert np.abs(oracle.unbiased_iou(b1, b2, prec='kernel') - g['unbiased']).max() < 5e-6
+    assert np.array_equal(oracle.iou_aligned(b1, b2, variant='sph_iou'), g['sph'])
+    assert np.array_equal(oracle.iou_aligned(b1, b2, variant='fov_iou'), g['fov'])
+
+
+@pytest.mark.gpu
+def test_gpu_reference_sample_pairs_other_backends():
+    import sph_retina_amd.iou as I
+    g = load_golden('samples7_backends')
+    t1, t2 = cu(g['b1']), cu(g['b2'])
+    assert np.abs(I.unbiased_iou(t1, t2, is_aligned=True).cpu().numpy() - g['unbiased64']).max() < 1e-6
+    assert np.abs(I.unbiased_iou(t1, t2).cpu().numpy() - g['unbiased_pw']).max() < 5e-6
+    assert np.abs(I.sph_iou(t1, t2, is_aligned=True).cpu().numpy() - g['sph']).max() < 1e-6
+    assert np.abs(I.fov_iou(t1, t2, is_aligned=True).cpu().numpy() - g['fov']).max() < 1e-6
+    # input immutability (tests/test_all_ious.py:322-332)
+    assert torch.equal(t1, cu(g['b1'])) and torch.equal(t2, cu(g['b2']))
