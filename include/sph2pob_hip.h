@@ -147,6 +147,16 @@ int sph2pob_nms_max_boxes(void);
 int64_t sph2pob_nms_workspace_bytes(int64_t k);
 int sph2pob_nms_f32(const float* boxes_sorted, const int64_t* cls_sorted, int64_t k, int box_dim, int variant,
                     float iou_threshold, void* workspace, unsigned char* keep, void* stream);
+/* Same with a caller-supplied bound on the largest class segment (boxes of one class): the suppression matrix is then
+ * k x (max_segment / 64 + 2) words instead of k x k / 64, and k itself is unbounded (< 2^31); max_segment <=
+ * sph2pob_nms_max_boxes() (32 704).  cls_sorted == NULL means one segment (max_segment >= k).  Under-stating max_segment
+ * truncates suppression for the over-long segment (never an out-of-bounds access).  multiclass_nms hands ALL
+ * (box, class) candidates above score_thr to the NMS (sphdet/bbox/nms/utils.py:6-15): 5 000 boxes x 37 classes is
+ * beyond the one-matrix limit of sph2pob_nms_f32 but ~1 700 per class. */
+int64_t sph2pob_nms_segmented_workspace_bytes(int64_t k, int64_t max_segment);
+int sph2pob_nms_segmented_f32(const float* boxes_sorted, const int64_t* cls_sorted, int64_t k, int box_dim, int variant,
+                              float iou_threshold, int64_t max_segment, void* workspace, unsigned char* keep,
+                              void* stream);
 
 /*
  * MaxIoUAssigner epilogue on a (k, n) overlaps matrix (rows = GT, columns = boxes), SURVEY §8f-1.

@@ -50,6 +50,9 @@ SIGNATURES = {
     'sph2pob_nms_workspace_bytes': [_i64],
     'sph2pob_nms_f32': [_c_f32p, ctypes.c_void_p, _i64, _int, _int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
                         ctypes.c_void_p],
+    'sph2pob_nms_segmented_workspace_bytes': [_i64, _i64],
+    'sph2pob_nms_segmented_f32': [_c_f32p, ctypes.c_void_p, _i64, _int, _int, ctypes.c_float, _i64, ctypes.c_void_p,
+                                  ctypes.c_void_p, ctypes.c_void_p],
     'sph2pob_coder_encode_f32': [_c_f32p, _c_f32p, ctypes.c_void_p, ctypes.c_void_p, _c_f32p, _i64, _int,
                                  ctypes.c_void_p],
     'sph2pob_coder_decode_f32': [_c_f32p, _c_f32p, ctypes.c_void_p, ctypes.c_void_p, _c_f32p, _i64, _int, _int,
@@ -61,7 +64,7 @@ SIGNATURES = {
                                ctypes.c_void_p],
 }
 _RESTYPES = {'sph2pob_target_arch': ctypes.c_char_p, 'sph2pob_error_string': ctypes.c_char_p,
-             'sph2pob_nms_workspace_bytes': ctypes.c_int64, 'sph2pob_assign_workspace_bytes': ctypes.c_int64}
+             'sph2pob_nms_workspace_bytes': ctypes.c_int64, 'sph2pob_nms_segmented_workspace_bytes': ctypes.c_int64, 'sph2pob_assign_workspace_bytes': ctypes.c_int64}
 
 ABI_VERSION = 1
 

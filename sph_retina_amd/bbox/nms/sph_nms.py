@@ -25,15 +25,21 @@ def _nms_sorted(boxes_sorted, cls_sorted, iou_threshold, variant):
     """keep flags (uint8, K) for boxes sorted by (class, -score)."""
     k, dim = boxes_sorted.shape
     lib = _lib.lib()
-    if k > lib.sph2pob_nms_max_boxes():
-        raise ValueError(f'sph nms supports at most {lib.sph2pob_nms_max_boxes()} boxes per call, got {k}')
     dev = boxes_sorted.device
     keep = torch.empty((k,), dtype=torch.uint8, device=dev)
     if k == 0:
         return keep
-    ws = torch.empty((lib.sph2pob_nms_workspace_bytes(k) // 8,), dtype=torch.int64, device=dev)
-    G.call('sph2pob_nms_f32', dev, G.ptr(boxes_sorted), G.ptr(cls_sorted), ctypes.c_int64(k), dim, G.VARIANTS[variant],
-           ctypes.c_float(iou_threshold), G.ptr(ws), G.ptr(keep), G.stream_of(boxes_sorted))
+    # the suppression matrix is k x (largest class segment / 64 + 2) words: its width needs the largest segment on the
+    # host (one sync; the caller's nonzero() syncs anyway).  multiclass_nms hands over every (box, class) candidate
+    # above score_thr — far more than 32 768 rows in total, but a class segment stays small.
+    max_seg = k if cls_sorted is None else int(torch.unique_consecutive(cls_sorted, return_counts=True)[1].max())
+    limit = lib.sph2pob_nms_max_boxes()
+    if max_seg > limit:
+        raise ValueError(f'sph nms supports at most {limit} boxes per class, got {max_seg}')
+    ws = torch.empty((lib.sph2pob_nms_segmented_workspace_bytes(k, max_seg) // 8,), dtype=torch.int64, device=dev)
+    G.call('sph2pob_nms_segmented_f32', dev, G.ptr(boxes_sorted), G.ptr(cls_sorted), ctypes.c_int64(k), dim,
+           G.VARIANTS[variant], ctypes.c_float(iou_threshold), ctypes.c_int64(max_seg), G.ptr(ws), G.ptr(keep),
+           G.stream_of(boxes_sorted))
     return keep
 
 

@@ -358,11 +358,13 @@ template <int VARIANT, int DIM, bool FAST>
 __global__ __launch_bounds__(kBlock) void nms_mask_kernel(const float* __restrict__ boxes,
                                                          const int64_t* __restrict__ cls, int64_t k, int words,
                                                          float thr, unsigned long long* __restrict__ mask) {
-    // one wave per row i: only the words that hold later columns of row i's own class segment are evaluated
+    // one wave per row i: only the words that hold later columns of row i's own class segment are evaluated.
+    // Row layout: `words` u64 per row, word r of row i covers columns 64 * ((seg_start >> 6) + r) ...: indices are
+    // relative to the row's class segment, so the matrix is k x (largest segment / 64 + 2) instead of k x k / 64.
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + wave;
     if (i >= k) return;
-    int64_t seg_end = k;  // first index past row i's class segment (boxes are sorted by class)
+    int64_t seg_begin = 0, seg_end = k;  // row i's class segment [seg_begin, seg_end) (boxes are sorted by class)
     if (cls) {
         const int64_t ci = cls[i];
         int64_t lo = i + 1, hi = k;
@@ -371,16 +373,28 @@ __global__ __launch_bounds__(kBlock) void nms_mask_kernel(const float* __restric
             if (cls[mid] <= ci) lo = mid + 1; else hi = mid;
         }
         seg_end = lo;
+        lo = 0; hi = i;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if (cls[mid] < ci) lo = mid + 1; else hi = mid;
+        }
+        seg_begin = lo;
     }
-    const int w_first = (int)((i + 1) >> 6), w_last = (int)((seg_end - 1) >> 6);  // empty when seg_end == i + 1
+    const int64_t base = seg_begin >> 6;
+    // relative word range of the later columns; empty when seg_end == i + 1; clipped to the row (a caller that
+    // under-states the largest segment gets truncated suppression, never an out-of-bounds store)
+    const int64_t r_first = ((i + 1) >> 6) - base;
+    int64_t r_last = ((seg_end - 1) >> 6) - base;
+    if (r_last > words - 1) r_last = words - 1;
+    const bool none = seg_end <= i + 1;
     unsigned long long* row = mask + i * words;
     for (int w = lane; w < words; w += 64)
-        if (w < w_first || w > w_last || seg_end <= i + 1) row[w] = 0ull;
-    if (seg_end <= i + 1) return;
+        if (none || w < r_first || w > r_last) row[w] = 0ull;
+    if (none) return;
     float x[5];
     load_box<DIM>(boxes, i, x);
-    for (int w = w_first; w <= w_last; w++) {
-        const int64_t j = (int64_t)w * 64 + lane;
+    for (int64_t r = r_first; r <= r_last; r++) {
+        const int64_t j = (base + r) * 64 + lane;
         bool hit = false;
         if (j > i && j < seg_end) {
             float y[5];
@@ -388,11 +402,11 @@ __global__ __launch_bounds__(kBlock) void nms_mask_kernel(const float* __restric
             hit = pair_iou_sel<VARIANT, DIM, FAST>(x, y, MODE_IOU, EDGE_ARC, ANGLE_EQUATOR) > thr;
         }
         unsigned long long bits = __ballot(hit);
-        if (lane == 0) row[w] = bits;
+        if (lane == 0) row[r] = bits;
     }
 }
 
-constexpr int kNmsMaxWords = 512;  // K <= 32768 boxes per call
+constexpr int kNmsMaxWords = 512;  // <= 32768 boxes per class segment (the sweep's removed bit-vector lives in LDS)
 
 // Greedy sweep, one wave per CLASS SEGMENT (classes are independent): every wave looks at one row; only the first row
 // of a segment survives and sweeps that segment's 64-row blocks in order.  Inside a block the serial dependency is
@@ -417,12 +431,17 @@ __global__ __launch_bounds__(kBlock) void nms_sweep_kernel(const unsigned long l
         seg_end = lo;
     }
     unsigned long long* removed = removed_all[wave];
-    const int b_first = (int)(s >> 6), b_last = (int)((seg_end - 1) >> 6);
-    for (int w = b_first + lane; w <= b_last; w += 64) removed[w] = 0ull;
+    // blocks of 64 rows, numbered relative to the segment's first block (the mask rows use the same numbering)
+    const int64_t base = s >> 6;
+    int b_last = (int)(((seg_end - 1) >> 6) - base);
+    const int limit = (words < kNmsMaxWords ? words : kNmsMaxWords) - 1;
+    if (b_last > limit) b_last = limit;   // over-long segment: rows beyond the limit keep their initial 0 flags
+    for (int w = lane; w <= b_last; w += 64) removed[w] = 0ull;
+    for (int64_t r = s + (int64_t)(b_last + 1) * 64 - (s & 63) + lane; r < seg_end; r += 64) keep[r] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (int b = b_first; b <= b_last; b++) {
-        const int64_t row0 = (int64_t)b * 64, row = row0 + lane;
+    for (int b = 0; b <= b_last; b++) {
+        const int64_t row0 = (base + b) * 64, row = row0 + lane;
         const bool mine = row >= s && row < seg_end;
         const unsigned long long diag = mine ? mask[row * words + b] : 0ull;
         const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
@@ -785,15 +804,20 @@ int sph2pob_sum_f32(const float* x, int64_t n, float scale, float* out, float* w
     return launch_status();
 }
 
-int sph2pob_nms_max_boxes(void) { return kNmsMaxWords * 64; }
+int sph2pob_nms_max_boxes(void) { return kNmsMaxWords * 64 - 64; }  // per class segment (unaligned: L/64 + 2 words)
 
-int64_t sph2pob_nms_workspace_bytes(int64_t k) {
-    int64_t words = (k + 63) / 64;
-    return k * words * 8;
+static int64_t nms_row_words(int64_t k, int64_t max_segment) {
+    int64_t full = (k + 63) / 64, seg = (max_segment >> 6) + 2;  // an unaligned segment of L boxes spans <= L/64 + 2 words
+    return seg < full ? seg : full;
+}
+int64_t sph2pob_nms_workspace_bytes(int64_t k) { return k * nms_row_words(k, k) * 8; }
+int64_t sph2pob_nms_segmented_workspace_bytes(int64_t k, int64_t max_segment) {
+    return k * nms_row_words(k, max_segment < 1 ? 1 : max_segment) * 8;
 }
 
-int sph2pob_nms_f32(const float* boxes_sorted, const int64_t* cls_sorted, int64_t k, int box_dim, int variant_flags,
-                    float iou_threshold, void* workspace, unsigned char* keep, void* stream) {
+int sph2pob_nms_segmented_f32(const float* boxes_sorted, const int64_t* cls_sorted, int64_t k, int box_dim,
+                              int variant_flags, float iou_threshold, int64_t max_segment, void* workspace,
+                              unsigned char* keep, void* stream) {
     const int variant = variant_flags & 0xff;
     const bool fast = !(variant_flags & SPH2POB_FLAG_REFERENCE_ORDER);
     if (variant_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER)) return SPH2POB_ERR_OPTION;
@@ -801,11 +825,13 @@ int sph2pob_nms_f32(const float* boxes_sorted, const int64_t* cls_sorted, int64_
     if (variant != SPH2POB_VARIANT_STANDARD && variant != SPH2POB_VARIANT_EFFICIENT && variant != SPH2POB_VARIANT_UNBIASED &&
         variant != SPH2POB_VARIANT_NAIVE)
         return SPH2POB_ERR_OPTION;
-    if (k < 0 || k > (int64_t)kNmsMaxWords * 64) return SPH2POB_ERR_SIZE;
+    if (k < 0 || k > ((int64_t)1 << 31) - 64 || max_segment < 0 || max_segment > sph2pob_nms_max_boxes())
+        return SPH2POB_ERR_SIZE;
     if (k == 0) return SPH2POB_OK;
     if (!boxes_sorted || !workspace || !keep) return SPH2POB_ERR_NULL;
+    if (!cls_sorted && max_segment < k) return SPH2POB_ERR_SIZE;  // one segment: it is k long
     hipStream_t s = (hipStream_t)stream;
-    const int words = (int)((k + 63) / 64);
+    const int words = (int)nms_row_words(k, max_segment < 1 ? 1 : max_segment);
     unsigned long long* mask = (unsigned long long*)workspace;
     const int wpb = kBlock / 64;
     dim3 grid((unsigned)((k + wpb - 1) / wpb));
@@ -828,6 +854,13 @@ int sph2pob_nms_f32(const float* boxes_sorted, const int64_t* cls_sorted, int64_
     if (rc) return rc;
     hipLaunchKernelGGL(nms_sweep_kernel, dim3((unsigned)((k + wpb - 1) / wpb)), dim3(kBlock), 0, s, mask, cls_sorted, k, words, keep);
     return launch_status();
+}
+
+int sph2pob_nms_f32(const float* boxes_sorted, const int64_t* cls_sorted, int64_t k, int box_dim, int variant_flags,
+                    float iou_threshold, void* workspace, unsigned char* keep, void* stream) {
+    if (k > sph2pob_nms_max_boxes()) return SPH2POB_ERR_SIZE;
+    return sph2pob_nms_segmented_f32(boxes_sorted, cls_sorted, k, box_dim, variant_flags, iou_threshold, k, workspace, keep,
+                                     stream);
 }
 
 int64_t sph2pob_assign_workspace_bytes(int64_t k, int64_t n) {

@@ -96,3 +96,35 @@ def test_multiclass_nms_wrapper(N, oracle):
     flat_scores = ms[:, :-1].reshape(-1)
     np.testing.assert_allclose(dets[:, 4].cpu().numpy(), flat_scores[inds.cpu().numpy()], atol=0)
     assert (np.diff(dets[:, 4].cpu().numpy()) <= 0).all() and float(dets[:, 4].min()) > 0.3
+
+
+def test_many_candidates_beyond_one_matrix(N, oracle):
+    """multiclass_nms hands every (box, class) candidate above score_thr to the NMS (sphdet/bbox/nms/utils.py:6-15):
+    far more than 32 k rows in total, a few thousand per class — the segment-relative suppression matrix handles it."""
+    rng = np.random.default_rng(11)
+    k, ncls = 60000, 37
+    centres = oracle.generate_boxes(400, 3, alpha=(5, 40), beta=(5, 40))
+    b = centres[rng.integers(0, 400, k)] + rng.normal(0, 1.5, (k, 4)).astype(np.float32)
+    b[:, 0] %= 360
+    b[:, 1] = np.clip(b[:, 1], 1, 179)
+    b[:, 2:] = np.clip(b[:, 2:], 2, 120)
+    scores = rng.random(k).astype(np.float32)
+    idxs = rng.integers(0, ncls, k)
+    dets, keep = N.SphNMS()(cu(b), cu(scores), cu(idxs), dict(type='nms', iou_threshold=0.5, max_num=300))
+    keep = keep.cpu().numpy()
+    assert len(keep) == 300 and len(set(keep.tolist())) == 300
+    # check three classes completely against the restatement
+    for c in (0, 17, 36):
+        m = np.nonzero(idxs == c)[0]
+        ref = set(m[oracle.nms_op(b[m], scores[m], 0.5, variant='efficient')].tolist())
+        d_all, keep_all = N.SphNMS()(cu(b[m]), cu(scores[m]), cu(np.zeros(len(m), np.int64)), dict(iou_threshold=0.5))
+        got = set(m[keep_all.cpu().numpy()].tolist())
+        assert len(got ^ ref) <= 2, (c, len(got), len(ref))          # a borderline IoU may flip one decision
+    # and the joint call equals the per-class calls
+    full_d, full_k = N.SphNMS()(cu(b), cu(scores), cu(idxs), dict(type='nms', iou_threshold=0.5))
+    per = []
+    for c in range(ncls):
+        m = np.nonzero(idxs == c)[0]
+        _, kc = N.SphNMS()(cu(b[m]), cu(scores[m]), cu(np.zeros(len(m), np.int64)), dict(iou_threshold=0.5))
+        per.append(m[kc.cpu().numpy()])
+    assert set(np.concatenate(per).tolist()) == set(full_k.cpu().numpy().tolist())
