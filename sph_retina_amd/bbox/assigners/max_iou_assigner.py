@@ -17,18 +17,47 @@ from ... import _torch_glue as G
 from ...registry import BBOX_ASSIGNERS, build_iou_calculator
 
 
-class AssignResult:
-    """Minimal stand-in for mmdet's AssignResult (mmdet/core/bbox/assigners/assign_result.py): same field names."""
+class _AssignResult:
+    """Stand-in for mmdet's AssignResult (mmdet/core/bbox/assigners/assign_result.py) when mmdet is not importable:
+    the fields and the methods samplers use (`add_gt_`, extra properties, `info`)."""
 
     def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
         self.num_gts = num_gts
         self.gt_inds = gt_inds
         self.max_overlaps = max_overlaps
         self.labels = labels
+        self._extra_properties = {}
 
     @property
     def num_preds(self):
         return len(self.gt_inds)
+
+    def set_extra_property(self, key, value):
+        assert key not in self.info
+        self._extra_properties[key] = value
+
+    def get_extra_property(self, key):
+        return self._extra_properties.get(key, None)
+
+    @property
+    def info(self):
+        basic = {'num_gts': self.num_gts, 'num_preds': self.num_preds, 'gt_inds': self.gt_inds,
+                 'max_overlaps': self.max_overlaps, 'labels': self.labels}
+        basic.update(self._extra_properties)
+        return basic
+
+    def add_gt_(self, gt_labels):  # assign_result.py:192-206
+        self_inds = torch.arange(1, len(gt_labels) + 1, dtype=torch.long, device=gt_labels.device)
+        self.gt_inds = torch.cat([self_inds, self.gt_inds])
+        self.max_overlaps = torch.cat([self.max_overlaps.new_ones(len(gt_labels)), self.max_overlaps])
+        if self.labels is not None:
+            self.labels = torch.cat([gt_labels, self.labels])
+
+
+try:  # hand mmdet's samplers their own class when mmdet is present
+    from mmdet.core.bbox.assigners.assign_result import AssignResult
+except Exception:  # mmdet / mmcv not installed (this container)
+    AssignResult = _AssignResult
 
 
 def assign_wrt_overlaps(overlaps, gt_labels=None, pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0.0,
