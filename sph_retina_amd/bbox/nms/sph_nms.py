@@ -91,3 +91,24 @@ class SphNMS:
 
     def __call__(self, boxes, scores, idxs, nms_cfg, class_agnostic=False):
         return sph_batched_nms(boxes, scores, idxs, nms_cfg, self.variant, class_agnostic)
+
+
+class PlanarNMS:
+    """PlanarNMS(box_formator='sph2pix')(boxes, scores, idxs, nms_cfg, class_agnostic=True) — reference
+    sphdet/bbox/nms/planar_nms.py:7-19: the boxes drawn in ERP pixels (Sph2PlanarBoxTransform) go through mmcv's
+    `batched_nms`, i.e. greedy NMS on the planar IoU — the Naive-IoU of this package — and, unlike SphNMS, across classes
+    by default (`class_agnostic=True`, overridable from `nms_cfg` as in mmcv).  Served by the same two kernels with the
+    naive variant.  mmcv is absent here: `batched_nms` is restated from its published behaviour (suppress IoU > thr,
+    result in descending score order, `max_num`) — parity unpinned."""
+
+    def __init__(self, box_formator='sph2pix'):
+        if box_formator != 'sph2pix':
+            raise NotImplementedError("PlanarNMS: only box_formator='sph2pix' is served by sph_retina_amd")
+        self.box_formator = box_formator
+
+    def __call__(self, boxes, scores, idxs, nms_cfg, class_agnostic=True):
+        nms_cfg_ = dict(nms_cfg)
+        class_agnostic = nms_cfg_.pop('class_agnostic', class_agnostic)
+        if class_agnostic:
+            idxs = torch.zeros_like(idxs)
+        return sph_batched_nms(boxes, scores, idxs, nms_cfg_, 'naive', class_agnostic)

@@ -128,3 +128,24 @@ def test_many_candidates_beyond_one_matrix(N, oracle):
         _, kc = N.SphNMS()(cu(b[m]), cu(scores[m]), cu(np.zeros(len(m), np.int64)), dict(iou_threshold=0.5))
         per.append(m[kc.cpu().numpy()])
     assert set(np.concatenate(per).tolist()) == set(full_k.cpu().numpy().tolist())
+
+
+def test_planar_nms_is_naive_iou_nms_class_agnostic_by_default(N, oracle):
+    rng = np.random.default_rng(5)
+    centres = oracle.generate_boxes(30, 2, alpha=(8, 50), beta=(8, 50))
+    k = 500
+    b = centres[rng.integers(0, 30, k)] + rng.normal(0, 2.0, (k, 4)).astype(np.float32)
+    b[:, 0] %= 360
+    b[:, 1] = np.clip(b[:, 1], 1, 179)
+    b[:, 2:] = np.clip(b[:, 2:], 2, 120)
+    scores, idxs = rng.random(k).astype(np.float32), rng.integers(0, 5, k)
+    cfg = dict(type='nms', iou_threshold=0.5)
+    d_ag, k_ag = N.PlanarNMS()(cu(b), cu(scores), cu(idxs), cfg)                       # across classes
+    rd, rk = oracle.batched_nms(b, scores, np.zeros(k, np.int64), 0.5, variant='naive')
+    assert np.array_equal(k_ag.cpu().numpy(), rk)
+    np.testing.assert_allclose(d_ag.cpu().numpy(), rd, atol=0)
+    d_pc, k_pc = N.PlanarNMS()(cu(b), cu(scores), cu(idxs), dict(cfg, class_agnostic=False))
+    rd, rk = oracle.batched_nms(b, scores, idxs, 0.5, variant='naive')
+    assert np.array_equal(k_pc.cpu().numpy(), rk) and len(rk) >= len(k_ag)
+    with pytest.raises(NotImplementedError):
+        N.PlanarNMS('sph2tan')
