@@ -39,13 +39,41 @@ template <bool R>
 SPH_DEV double ubf(double x) {
     return R ? (double)(float)x : x;
 }
+// sin and cos of |x| <~ 8 rad in double to ~1 ulp: quadrant reduction by pi/2 in two pieces (the first has 33
+// significant bits, so k * PIO2_1 is exact for the |k| <= 5 that occur here) and the fdlibm kernel polynomials on
+// [-pi/4, pi/4].  The library sincos carries a Payne-Hanek path for huge arguments and costs ~195 instructions, ten
+// calls per pair: a third of the kernel.
+SPH_DEV void sincos_d(double x, double& s, double& c) {
+    const double k = rint(x * 6.36619772367581382433e-01);             // 2 / pi
+    double r = fma(-k, 1.57079632673412561417e+00, x);                 // PIO2_1
+    r = fma(-k, 6.07710050650619224932e-11, r);                        // PIO2_1T
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double sp = fma(r * z, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    const double cp = w + (((1.0 - w) - hz) + z * (z * pc));
+    const int q = (int)k & 3;
+    const double a = (q & 1) ? cp : sp, b = (q & 1) ? sp : cp;
+    s = (q & 2) ? -a : a;
+    c = ((q + 1) & 2) ? -b : b;
+}
+
 template <bool R>
 SPH_DEV void ub_sincos(double x, double& s, double& c) {
     if (R) {
         s = (double)sinf((float)x);
         c = (double)cosf((float)x);
     } else {
-        sincos(x, &s, &c);
+        sincos_d(x, s, c);
     }
 }
 SPH_DEV double ub_acos_clip(double c) { return acos(fmin(fmax(c, -1.0), 1.0)); }
