@@ -32,7 +32,8 @@ def _nms_sorted(boxes_sorted, cls_sorted, iou_threshold, variant):
     # the suppression matrix is k x (largest class segment / 64 + 2) words: its width needs the largest segment on the
     # host (one sync; the caller's nonzero() syncs anyway).  multiclass_nms hands over every (box, class) candidate
     # above score_thr — far more than 32 768 rows in total, but a class segment stays small.
-    max_seg = k if cls_sorted is None else int(torch.unique_consecutive(cls_sorted, return_counts=True)[1].max())
+    # Small inputs take the full k x k/64 layout (<= 8 MB) and skip that sync.
+    max_seg = k if cls_sorted is None or k <= 8192 else int(torch.unique_consecutive(cls_sorted, return_counts=True)[1].max())
     limit = lib.sph2pob_nms_max_boxes()
     if max_seg > limit:
         raise ValueError(f'sph nms supports at most {limit} boxes per class, got {max_seg}')

@@ -503,7 +503,12 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return v;
 }
 
-// A: one thread per column (anchor): running max / first argmax over the k rows, and per-wave row partials
+// A: one thread per column (anchor): running max / first argmax over the k rows, and per-wave row partials.
+// Rows are taken 32 at a time: 32 independent coalesced loads per lane, then a transposing butterfly — at the stage
+// with lane mask M a lane keeps the lower (bit clear) or upper (bit set) half of its rows and receives the partner's
+// copy of that half — leaves lane L with the wave-wide maximum key of row (L >> 1) after 31 + 1 exchanges, instead of
+// one 6-step wave reduction per row (192 exchanges per 32 rows).
+constexpr int kAssignRows = 32;
 __global__ __launch_bounds__(kBlock) void assign_cols_kernel(const float* __restrict__ ov, int k, int64_t n,
                                                             float* __restrict__ max_ov, int64_t* __restrict__ argmax_ov,
                                                             unsigned long long* __restrict__ partial, int nparts) {
@@ -511,13 +516,35 @@ __global__ __launch_bounds__(kBlock) void assign_cols_kernel(const float* __rest
     const int lane = threadIdx.x & 63;
     const int part = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const bool valid = j < n;
+    const int64_t jc = valid ? j : n - 1;   // clamp the address, mask the value
     float best = -__builtin_inff();
     int besti = 0;
-    for (int i = 0; i < k; i++) {
-        float v = valid ? ov[(int64_t)i * n + j] : -__builtin_inff();
-        if (v > best) { best = v; besti = i; }
-        unsigned long long key = wave_max_u64(valid ? pack_max_key(v, j) : 0ull);
-        if (lane == 0) partial[(int64_t)i * nparts + part] = key;
+    for (int r0 = 0; r0 < k; r0 += kAssignRows) {
+        unsigned long long key[kAssignRows];
+#pragma unroll
+        for (int t = 0; t < kAssignRows; t++) {
+            const int i = r0 + t;
+            const bool live = valid && i < k;
+            const float v = live ? ov[(int64_t)(i < k ? i : k - 1) * n + jc] : -__builtin_inff();
+            if (v > best) { best = v; besti = i; }
+            key[t] = live ? pack_max_key(v, j) : 0ull;
+        }
+#pragma unroll
+        for (int cnt = kAssignRows, m = 32; cnt > 1; cnt >>= 1, m >>= 1) {
+            const bool upper = (lane & m) != 0;
+            const int half = cnt >> 1;
+#pragma unroll
+            for (int t = 0; t < half; t++) {
+                const unsigned long long mine = upper ? key[t + half] : key[t];
+                const unsigned long long send = upper ? key[t] : key[t + half];
+                const unsigned long long recv = __shfl_xor(send, m, 64);
+                key[t] = recv > mine ? recv : mine;
+            }
+        }
+        const unsigned long long other = __shfl_xor(key[0], 1, 64);
+        const unsigned long long row_max = other > key[0] ? other : key[0];
+        const int i = r0 + (lane >> 1);
+        if ((lane & 1) == 0 && i < k) partial[(int64_t)i * nparts + part] = row_max;
     }
     if (valid) { max_ov[j] = best; argmax_ov[j] = besti; }
 }
@@ -559,11 +586,15 @@ __global__ __launch_bounds__(kBlock) void assign_finalize_kernel(const float* __
     if (m >= neg_lo && m < neg_hi) a = 0;
     if (m >= pos_thr) a = argmax_ov[j] + 1;
     if (low_quality) {
-        for (int i = 0; i < k; i++) {
-            const float g = gt_max[i];
-            if (g >= min_pos) {
-                if (assign_all ? (ov[(int64_t)i * n + j] == g) : (gt_argmax[i] == j)) a = i + 1;
+        if (assign_all) {   // the column is re-read: keep 8 independent loads in flight
+#pragma unroll 8
+            for (int i = 0; i < k; i++) {
+                const float g = gt_max[i];
+                if (ov[(int64_t)i * n + j] == g && g >= min_pos) a = i + 1;
             }
+        } else {
+            for (int i = 0; i < k; i++)
+                if (gt_max[i] >= min_pos && gt_argmax[i] == j) a = i + 1;
         }
     }
     gt_inds[j] = a;
