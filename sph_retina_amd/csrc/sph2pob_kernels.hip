@@ -16,13 +16,15 @@ using namespace sph2pob;
 constexpr int kBlock = 256;  // 4 waves of 64 lanes
 constexpr int kCUs = 256;    // MI355X: 8 XCDs x 32 CUs
 
-// tuning knobs (environment, read once): SPH2POB_NO_COMPACT=1 disables the compacting kernel,
-// SPH2POB_SLICES_PER_WAVE sets how many 64-pair slices each wave of the compacting kernel walks
+// tuning / A-B knobs (environment, read once at load): SPH2POB_NO_COMPACT=1 disables the compacting kernels,
+// SPH2POB_NO_PREFETCH=1 the register prefetch, SPH2POB_SLICES_PER_WAVE=s / SPH2POB_WGS_PER_CU=k override the aligned
+// kernel's grid rule (s slices per wave, or exactly k workgroups per CU), SPH2POB_PW_ROWS the pairwise kernel's rows
+// per workgroup
 static bool g_no_compact = getenv("SPH2POB_NO_COMPACT") != nullptr;
 static bool g_prefetch = getenv("SPH2POB_NO_PREFETCH") == nullptr;
 static int g_pw_rows = getenv("SPH2POB_PW_ROWS") ? atoi(getenv("SPH2POB_PW_ROWS")) : 0;
-static int g_slices_per_wave = getenv("SPH2POB_SLICES_PER_WAVE") ? atoi(getenv("SPH2POB_SLICES_PER_WAVE")) : 4;
-static int g_wgs_per_cu = getenv("SPH2POB_WGS_PER_CU") ? atoi(getenv("SPH2POB_WGS_PER_CU")) : 0;  // experiment knob
+static int g_slices_per_wave = getenv("SPH2POB_SLICES_PER_WAVE") ? atoi(getenv("SPH2POB_SLICES_PER_WAVE")) : 0;
+static int g_wgs_per_cu = getenv("SPH2POB_WGS_PER_CU") ? atoi(getenv("SPH2POB_WGS_PER_CU")) : 0;
 
 template <int DIM>
 __device__ __forceinline__ void load_box(const float* __restrict__ p, int64_t i, float (&b)[5]) {
@@ -661,7 +663,7 @@ struct AlignedLaunch {
             // one 64-pair slice per wave.
             int64_t slices = (n + 63) / 64;
             int64_t wgs = (slices + 3) / 4;
-            if (g_slices_per_wave > 0 && getenv("SPH2POB_SLICES_PER_WAVE")) wgs = (slices + 4 * g_slices_per_wave - 1) / (4 * g_slices_per_wave);
+            if (g_slices_per_wave > 0) wgs = (slices + 4 * g_slices_per_wave - 1) / (4 * g_slices_per_wave);
             else if (wgs > kCUs) { wgs = (wgs + kCUs - 1) / kCUs * kCUs; if (wgs > kCUs * 6) wgs = kCUs * 6; }
             if (wgs > kCUs * 7) wgs = kCUs * 7;
             if (g_wgs_per_cu > 0) wgs = kCUs * g_wgs_per_cu;
