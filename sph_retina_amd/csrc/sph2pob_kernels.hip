@@ -14,12 +14,25 @@ namespace {
 using namespace sph2pob;
 
 constexpr int kBlock = 256;  // 4 waves of 64 lanes
-constexpr int kCUs = 256;    // MI355X: 8 XCDs x 32 CUs
+constexpr int kCUsDefault = 256;  // MI355X in SPX mode: 8 XCDs x 32 CUs
 
 // tuning / A-B knobs (environment, read once at load): SPH2POB_NO_COMPACT=1 disables the compacting kernels,
 // SPH2POB_NO_PREFETCH=1 the register prefetch, SPH2POB_SLICES_PER_WAVE=s / SPH2POB_WGS_PER_CU=k override the aligned
 // kernel's grid rule (s slices per wave, or exactly k workgroups per CU), SPH2POB_PW_ROWS the pairwise kernel's rows
 // per workgroup
+// CU count of the current device (a partitioned MI355X exposes fewer); queried once, no synchronisation involved
+static int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = kCUsDefault;
+    }
+    return n;
+}
 static bool g_no_compact = getenv("SPH2POB_NO_COMPACT") != nullptr;
 static bool g_prefetch = getenv("SPH2POB_NO_PREFETCH") == nullptr;
 static int g_pw_rows = getenv("SPH2POB_PW_ROWS") ? atoi(getenv("SPH2POB_PW_ROWS")) : 0;
@@ -661,6 +674,7 @@ struct AlignedLaunch {
             // best or within noise of the best from 125 k to 8 M pairs; (iii) small launches want one slice per wave
             // rather than full survivor stacks.  Hence: whole multiples of the CU count, at most 6 per CU, at least
             // one 64-pair slice per wave.
+            const int64_t kCUs = cu_count();
             int64_t slices = (n + 63) / 64;
             int64_t wgs = (slices + 3) / 4;
             if (g_slices_per_wave > 0) wgs = (slices + 4 * g_slices_per_wave - 1) / (4 * g_slices_per_wave);
