@@ -12,6 +12,9 @@ one RCCL all_gather_into_tensor per step, double-buffered so that the collective
 the kernel of step i+1 (4 MB per rank per step: wire + launch time of the collective exceeds the 10 us kernel, so that
 variant is communication-bound by construction).
 `value` = pairs processed by all ranks / max-over-ranks wall time.  Weak scaling (per-GPU work fixed).
+Timing: W warm-up steps (topped up to 3 000 untimed steps — the clocks only settle after a few thousand back-to-back
+launches; the count is reported as config.untimed_steps_before_timing), barrier + synchronize, exactly K timed steps,
+barrier + synchronize, max over ranks.
 
 Extra objects on the JSON line:
   roofline      the dominant kernel (iou_aligned) against the HBM roofline: algorithmic bytes = 36 B/pair
@@ -35,6 +38,9 @@ PAIRS_PER_GPU = 1_000_000
 BYTES_PER_PAIR = 36          # aligned BFoV: 2 * 16 B read + 4 B written
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 VARIANT = 'standard'
+
+
+CLOCK_SETTLE_STEPS = 3000
 
 
 def rank_env():
@@ -163,7 +169,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
+    # W warm-up steps as asked, topped up to CLOCK_SETTLE_STEPS untimed steps: the GPU clocks only settle after a few
+    # thousand back-to-back launches (20 launches in a row run at 10.9 us each, 5 000 at 9.3 us), whatever W is
+    for i in range(max(args.warmup, CLOCK_SETTLE_STEPS)):
         step(i)
     barrier()
     t0 = time.perf_counter()
@@ -204,7 +212,8 @@ def main():
             'data': 'synthetic',
             'config': {'workload': f'{n:,} uniform random BFoV pairs per GPU, sph2pob_{args.variant}_iou aligned '
                                    f'(BASELINE configs[1]{"; x%d shards" % world if world > 1 else ""}{" + RCCL all-gather of the shards, pipelined one step deep" if gather else ""})',
-                       'pairs_per_gpu': n, 'variant': args.variant, 'arithmetic': args.arithmetic, 'parallelism': f'shard{world}', 'gather': bool(gather)},
+                       'pairs_per_gpu': n, 'variant': args.variant, 'arithmetic': args.arithmetic, 'parallelism': f'shard{world}', 'gather': bool(gather),
+                       'untimed_steps_before_timing': max(args.warmup, CLOCK_SETTLE_STEPS)},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(),
                          'kernel': 'iou_aligned_compact_kernel' if args.arithmetic == 'fast' and args.variant != 'legacy'
