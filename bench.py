@@ -186,7 +186,7 @@ def main():
 
     # dominant-kernel duration: HIP events on the launch stream around K back-to-back launches (no collective)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    k_launch = max(args.steps, 50)
+    k_launch = max(args.steps, 1000)   # long enough for a stable average whatever K is
     torch.cuda.synchronize(dev)
     ev0.record(stream)
     for _ in range(k_launch):
