@@ -236,3 +236,52 @@ def test_sph_iou_loss_legacy_postmaps(L, mode):
     assert torch.allclose(pred.grad, p2.grad, rtol=1e-4, atol=1e-7)
     from sph_retina_amd.registry import build_loss
     assert isinstance(build_loss(dict(type='SphIoULossLegacy')), SphIoULossLegacy)
+
+
+def test_mmrotate_loss_bodies_are_wrapped_when_mmrotate_is_present(L, monkeypatch):
+    """Sph2PobGDLoss / Sph2PobKFLoss = mmrotate's GDLoss / KFLoss behind the Sph2PobTransfrom decorator (reference
+    sph2pob_gd_loss.py:7-9, sph2pob_kf_loss.py:8-26).  mmrotate is absent here, so a stand-in module checks the wiring:
+    the bodies receive planar (n, 5) boxes in radians, KFLoss gets the swapped decode arguments, gradients reach the
+    spherical inputs through the fused transform backward."""
+    import importlib
+    import sys
+    import types
+    import torch.nn as nn
+    seen = {}
+
+    class GDLoss(nn.Module):
+        def __init__(self, loss_type='gwd', **kw):
+            super().__init__()
+            self.loss_type = loss_type
+
+        def forward(self, pred, target, weight=None, **kw):
+            seen['gd'] = (pred.shape, target.shape)
+            return ((pred - target) ** 2).sum(-1).mean()
+
+    class KFLoss(nn.Module):
+        def forward(self, pred, target, weight=None, pred_decode=None, targets_decode=None, **kw):
+            seen['kf'] = (pred_decode is target, targets_decode is pred)
+            return (pred - target).abs().sum(-1).mean()
+    for name in ('mmrotate', 'mmrotate.models'):
+        monkeypatch.setitem(sys.modules, name, types.ModuleType(name))
+    fake = types.ModuleType('mmrotate.models.losses')
+    fake.GDLoss, fake.KFLoss = GDLoss, KFLoss
+    monkeypatch.setitem(sys.modules, 'mmrotate.models.losses', fake)
+    import sph_retina_amd.losses.sph2pob_mmrotate_losses as M
+    M = importlib.reload(M)
+    try:
+        assert M.__all__ == ['Sph2PobGDLoss', 'Sph2PobKFLoss']
+        g = load_golden('loss_bfov')
+        pred, target = cu(g['pred'], True), cu(g['target'])
+        loss = M.Sph2PobGDLoss(loss_type='kld')(pred, target)
+        loss.backward()
+        assert seen['gd'] == ((pred.size(0), 5), (pred.size(0), 5))
+        assert torch.isfinite(pred.grad).all() and float(pred.grad.abs().max()) > 0
+        p2 = cu(g['pred'], True)
+        M.Sph2PobKFLoss()(p2, target).backward()
+        assert seen['kf'] == (True, True) and torch.isfinite(p2.grad).all()
+        from sph_retina_amd.registry import LOSSES
+        assert LOSSES.get('Sph2PobGDLoss') is M.Sph2PobGDLoss
+    finally:
+        monkeypatch.undo()
+        importlib.reload(M)
