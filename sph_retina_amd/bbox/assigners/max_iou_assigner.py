@@ -98,7 +98,7 @@ def assign_wrt_overlaps(overlaps, gt_labels=None, pos_iou_thr=0.5, neg_iou_thr=0
     return res
 
 
-@BBOX_ASSIGNERS.register_module()
+@BBOX_ASSIGNERS.register_module(force=True)
 class SphMaxIoUAssigner:
     """Same constructor as mmdet's MaxIoUAssigner (:45-65); `iou_calculator` defaults to the Sph2Pob standard IoU."""
 

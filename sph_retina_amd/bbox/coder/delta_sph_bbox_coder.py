@@ -112,13 +112,13 @@ class _DeltaSphCoderBase:
                           self.add_ctr_clamp, self.ctr_clamp, box_dim=self.box_dim)
 
 
-@BBOX_CODERS.register_module()
+@BBOX_CODERS.register_module(force=True)
 class DeltaXYWHSphBBoxCoder(_DeltaSphCoderBase):
     """(theta, phi, alpha, beta) <-> (d_theta, d_phi, d_alpha, d_beta); delta_xywh_sph_bbox_coder.py:10-113."""
     box_dim = 4
 
 
-@BBOX_CODERS.register_module()
+@BBOX_CODERS.register_module(force=True)
 class DeltaXYWHASphBBoxCoder(_DeltaSphCoderBase):
     """(theta, phi, alpha, beta, gamma) <-> five deltas, the fifth in radians; delta_xywha_rsph_bbox_coder.py:10-113."""
     box_dim = 5

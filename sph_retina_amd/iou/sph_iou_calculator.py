@@ -17,7 +17,7 @@ _HIP_BACKENDS = {'sph2pob_standard_iou': sph2pob_standard_iou, 'sph2pob_legacy_i
                  'unbiased_iou': unbiased_iou, 'naive_iou': naive_iou}
 
 
-@IOU_CALCULATORS.register_module()
+@IOU_CALCULATORS.register_module(force=True)
 class SphOverlaps2D(object):
     """2D Overlaps calculator for spherical boxes (reference: sph_iou_calculator.py:8-56)."""
 

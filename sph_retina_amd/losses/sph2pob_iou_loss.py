@@ -110,13 +110,13 @@ class OBBIoULoss(nn.Module):
                                 avg_factor=avg_factor, loss_weight=self.loss_weight)
 
 
-@LOSSES.register_module()
+@LOSSES.register_module(force=True)
 class Sph2PobIoULoss(OBBIoULoss):
     """dict(type='Sph2PobIoULoss', mode='ciou', loss_weight=1.0) — reference sph2pob_iou_loss.py:218-235."""
     pass
 
 
-@LOSSES.register_module()
+@LOSSES.register_module(force=True)
 class SphIoULoss(OBBIoULoss):
     """The reference's SphIoULoss (sph2pob_iou_loss.py:238-292) cannot be constructed at HEAD (its default
     iou_calculator is rejected by its own assert) and only implements mode='iou' through the Sph2Pob IoU.  Served
@@ -128,7 +128,7 @@ class SphIoULoss(OBBIoULoss):
         super().__init__(mode=mode, eps=eps, reduction=reduction, loss_weight=loss_weight)
 
 
-@LOSSES.register_module()
+@LOSSES.register_module(force=True)
 class SphIoULossLegacy(nn.Module):
     """`@Sph2PobTransfrom() class SphIoULossLegacy(RotatedIoULoss)` (reference sph2pob_iou_loss.py:199-216): mmrotate
     0.3.2's RotatedIoULoss — `-log(IoU)` ('log', default), `1 - IoU` ('linear') or `1 - IoU^2` ('square') of the

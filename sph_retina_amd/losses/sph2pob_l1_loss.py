@@ -58,7 +58,7 @@ def _reduce(loss, reduction, avg_factor):
     return loss
 
 
-@LOSSES.register_module()
+@LOSSES.register_module(force=True)
 class Sph2PobL1Loss(nn.Module):
     """Sph2PobL1Loss(encode=True, swap=False, angle_modifier='original', reduction='mean', loss_weight=1.0)
     .forward(pred, target, weight=None, avg_factor=None, reduction_override=None) on SPHERICAL boxes (n, 4|5) deg."""
