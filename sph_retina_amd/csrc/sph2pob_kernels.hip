@@ -423,75 +423,83 @@ __global__ __launch_bounds__(kBlock) void nms_mask_kernel(const float* __restric
 
 constexpr int kNmsMaxWords = 512;  // <= 32768 boxes per class segment (the sweep's removed bit-vector lives in LDS)
 
-// Greedy sweep, one wave per CLASS SEGMENT (classes are independent): every wave looks at one row; only the first row
-// of a segment survives and sweeps that segment's 64-row blocks in order.  Inside a block the serial dependency is
-// resolved on the 64x64 diagonal block held one row per lane (v_readlane + scalar bit operations only); the kept
-// rows are then OR-ed into the wave's "removed" bit-vector (LDS) with lanes owning words and 16 row loads in flight.
+// Greedy sweep, one WORKGROUP per class segment (classes are independent).  Every workgroup looks at 4 candidate rows;
+// a row that starts a class segment makes the whole workgroup sweep that segment's 64-row blocks in order:
+//   wave 0 resolves the serial dependency inside the block on the 64x64 diagonal block held one row per lane
+//   (v_readlane + scalar bit operations only) and publishes the kept rows of the block;
+//   all 256 threads then OR the kept rows' later words into the segment's "removed" bit-vector (LDS): a task is
+//   (word, group of 16 rows) — 16 independent loads in flight per thread — combined with an LDS atomic OR.
+// (With one wave per segment a thread owned a word and walked its 64 rows in 4 dependent batches: 2.4 us per block.)
 __global__ __launch_bounds__(kBlock) void nms_sweep_kernel(const unsigned long long* __restrict__ mask,
                                                            const int64_t* __restrict__ cls, int64_t k, int words,
                                                            unsigned char* __restrict__ keep) {
-    __shared__ unsigned long long removed_all[kBlock / 64][kNmsMaxWords];
+    __shared__ unsigned long long removed[kNmsMaxWords];
+    __shared__ unsigned long long kept_sh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t s = (int64_t)blockIdx.x * (kBlock / 64) + wave;  // candidate segment head
-    if (s >= k) return;
-    if (cls ? (s > 0 && cls[s] == cls[s - 1]) : (s > 0)) return;
-    int64_t seg_end = k;
-    if (cls) {
-        const int64_t cs = cls[s];
-        int64_t lo = s + 1, hi = k;
-        while (lo < hi) {
-            int64_t mid = (lo + hi) >> 1;
-            if (cls[mid] <= cs) lo = mid + 1; else hi = mid;
-        }
-        seg_end = lo;
-    }
-    unsigned long long* removed = removed_all[wave];
-    // blocks of 64 rows, numbered relative to the segment's first block (the mask rows use the same numbering)
-    const int64_t base = s >> 6;
-    int b_last = (int)(((seg_end - 1) >> 6) - base);
-    const int limit = (words < kNmsMaxWords ? words : kNmsMaxWords) - 1;
-    if (b_last > limit) b_last = limit;   // over-long segment: rows beyond the limit keep their initial 0 flags
-    for (int w = lane; w <= b_last; w += 64) removed[w] = 0ull;
-    for (int64_t r = s + (int64_t)(b_last + 1) * 64 - (s & 63) + lane; r < seg_end; r += 64) keep[r] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int b = 0; b <= b_last; b++) {
-        const int64_t row0 = (base + b) * 64, row = row0 + lane;
-        const bool mine = row >= s && row < seg_end;
-        const unsigned long long diag = mine ? mask[row * words + b] : 0ull;
-        const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-        const unsigned long long rem_v = removed[b];
-        // scalar (SGPR) state of the serial chain; rows of the block outside this segment start out "removed"
-        // (the readlane/readfirstlane builtins return int: cast before widening, or bit 31 sign-extends)
-        unsigned long long rem = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(rem_v >> 32)) << 32) |
-                                 (unsigned)__builtin_amdgcn_readfirstlane((unsigned)rem_v);
-        rem |= ~__ballot(mine);
-        unsigned long long keepbits = 0ull;
-        for (int r = 0; r < 64; r++) {
-            if (!((rem >> r) & 1ull)) {
-                keepbits |= 1ull << r;
-                rem |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, r) << 32) |
-                       (unsigned)__builtin_amdgcn_readlane(dlo, r);
+    for (int cand = 0; cand < kBlock / 64; cand++) {   // workgroup-uniform loop and conditions: barriers are safe
+        const int64_t s = (int64_t)blockIdx.x * (kBlock / 64) + cand;  // candidate segment head
+        if (s >= k) break;
+        if (cls ? (s > 0 && cls[s] == cls[s - 1]) : (s > 0)) continue;
+        int64_t seg_end = k;
+        if (cls) {
+            const int64_t cs = cls[s];
+            int64_t lo = s + 1, hi = k;
+            while (lo < hi) {
+                int64_t mid = (lo + hi) >> 1;
+                if (cls[mid] <= cs) lo = mid + 1; else hi = mid;
             }
+            seg_end = lo;
         }
-        if (mine) keep[row] = (unsigned char)((keepbits >> lane) & 1ull);
-        for (int w = b + 1 + lane; w <= b_last; w += 64) {
-            const unsigned long long* col = mask + row0 * words + w;
-            unsigned long long acc = 0ull;
-            for (int r0 = 0; r0 < 64; r0 += 16) {
+        // blocks of 64 rows, numbered relative to the segment's first block (the mask rows use the same numbering)
+        const int64_t base = s >> 6;
+        int b_last = (int)(((seg_end - 1) >> 6) - base);
+        const int limit = (words < kNmsMaxWords ? words : kNmsMaxWords) - 1;
+        if (b_last > limit) b_last = limit;   // over-long segment: rows beyond the limit keep 0 flags
+        __syncthreads();                      // the previous candidate's sweep is done with the shared state
+        for (int w = threadIdx.x; w <= b_last; w += kBlock) removed[w] = 0ull;
+        for (int64_t r = (base + b_last + 1) * 64 + threadIdx.x; r < seg_end; r += kBlock) keep[r] = 0;
+        __syncthreads();
+        for (int b = 0; b <= b_last; b++) {
+            const int64_t row0 = (base + b) * 64;
+            if (wave == 0) {
+                const int64_t row = row0 + lane;
+                const bool mine = row >= s && row < seg_end;
+                const unsigned long long diag = mine ? mask[row * words + b] : 0ull;
+                const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+                // scalar (SGPR) state of the serial chain; rows of the block outside this segment start out "removed"
+                // (the readlane builtins return int: cast before widening, or bit 31 sign-extends)
+                unsigned long long rem = removed[b] | ~__ballot(mine);
+                rem = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(rem >> 32)) << 32) |
+                      (unsigned)__builtin_amdgcn_readfirstlane((unsigned)rem);
+                unsigned long long keepbits = 0ull;
+                for (int r = 0; r < 64; r++) {
+                    if (!((rem >> r) & 1ull)) {
+                        keepbits |= 1ull << r;
+                        rem |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, r) << 32) |
+                               (unsigned)__builtin_amdgcn_readlane(dlo, r);
+                    }
+                }
+                if (mine) keep[row] = (unsigned char)((keepbits >> lane) & 1ull);
+                if (lane == 0) kept_sh = keepbits;
+            }
+            __syncthreads();
+            const unsigned long long keepbits = kept_sh;
+            const int ntasks = (b_last - b) * 4;   // (later word, group of 16 rows)
+            for (int t = threadIdx.x; t < ntasks; t += kBlock) {
+                const int w = b + 1 + (t >> 2), r0 = (t & 3) * 16;
+                const unsigned bits = (unsigned)(keepbits >> r0) & 0xffffu;
+                if (bits == 0u) continue;
+                const unsigned long long* col = mask + (row0 + r0) * words + w;
                 unsigned long long v[16];
 #pragma unroll
-                for (int u = 0; u < 16; u++) {
-                    const int r = r0 + u;
-                    v[u] = ((keepbits >> r) & 1ull) ? col[(int64_t)r * words] : 0ull;
-                }
+                for (int u = 0; u < 16; u++) v[u] = ((bits >> u) & 1u) ? col[(int64_t)u * words] : 0ull;
+                unsigned long long acc = 0ull;
 #pragma unroll
                 for (int u = 0; u < 16; u++) acc |= v[u];
+                if (acc) atomicOr(&removed[w], acc);
             }
-            removed[w] |= acc;
+            __syncthreads();
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
