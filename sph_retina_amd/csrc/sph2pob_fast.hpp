@@ -200,17 +200,21 @@ SPH_DEV bool cull_pair(const CullBox& g, const CullBox& p) {
 template <int DIM>
 SPH_DEV bool fast_cull(const float (&g)[5], const float (&p)[5], int edge) {
 #pragma clang fp contract(fast)
-    float wg = fminf(g[2], 180.0f) * kDeg2Rad, hg = fminf(g[3], 180.0f) * kDeg2Rad;
-    float wp = fminf(p[2], 180.0f) * kDeg2Rad, hp = fminf(p[3], 180.0f) * kDeg2Rad;
+    // scale first, clamp second: the product is a canonical number, so the compiler does not have to quiet a possible
+    // signalling NaN of the loaded value (v_max x, x) in front of every v_min / v_max; same values (monotone rounding)
+    const float kPiHi = 180.0f * kDeg2Rad;
+    float wg = fminf(g[2] * kDeg2Rad, kPiHi), hg = fminf(g[3] * kDeg2Rad, kPiHi);
+    float wp = fminf(p[2] * kDeg2Rad, kPiHi), hp = fminf(p[3] * kDeg2Rad, kPiHi);
     if (edge != EDGE_ARC) { wg = edge_length(wg, edge); hg = edge_length(hg, edge); wp = edge_length(wp, edge); hp = edge_length(hp, edge); }
     const float dg = wg * wg + hg * hg, dp = wp * wp + hp * hp, prod = dg * dp;
     const float R2 = 0.25f * (dg + dp) + 0.5f * (prod * fast_rsq(prod)) + 9.01e-3f;
     const float cosR_lb = fmaf(fmaf(fmaf(-1.0f / 720.0f, R2, 1.0f / 24.0f), R2, -0.5f), R2, 1.0f);
     const float kRev = 1.0f / 360.0f;
-    const float phg = fminf(fmaxf(g[1], 0.0f), 180.0f), php = fminf(fmaxf(p[1], 0.0f), 180.0f);
-    const float thg = fminf(fmaxf(g[0], 0.0f), 360.0f), thp = fminf(fmaxf(p[0], 0.0f), 360.0f);
-    const float u = hw_cos_rev((phg - php) * kRev), v = hw_cos_rev((phg + php) * kRev);
-    const float cD = hw_cos_rev((thp - thg) * kRev);
+    // latitudes / longitudes in revolutions, clamped like the jitter clamps them (phi to [0, 180], theta to [0, 360] deg)
+    const float phg = fminf(fmaxf(g[1] * kRev, 0.0f), 0.5f), php = fminf(fmaxf(p[1] * kRev, 0.0f), 0.5f);
+    const float thg = fminf(fmaxf(g[0] * kRev, 0.0f), 1.0f), thp = fminf(fmaxf(p[0] * kRev, 0.0f), 1.0f);
+    const float u = hw_cos_rev(phg - php), v = hw_cos_rev(phg + php);
+    const float cD = hw_cos_rev(thp - thg);
     const float C = 0.5f * ((u + v) + (u - v) * cD);
     return (R2 < 8.9f) & (C < cosR_lb - 1e-4f);
 }
