@@ -245,11 +245,11 @@ SPH_DEV int fast_phase1(const float (&b1)[5], const float (&b2)[5], int edge, Fa
     if (trig) { trig->sg = sg; trig->cg = cg; trig->sp = sp; trig->cp = cp; trig->sD = sD; trig->cD = 1.0f - h2; }
     // exact early-out: circumscribed circles of the two planar rectangles cannot touch (margin covers both jitters
     // and the reference's own rounding of A); 1 - R^2/2 + R^4/24 - R^6/720 <= cos R
-    float d1 = r.wg * r.wg + r.hg * r.hg, d2 = r.wp * r.wp + r.hp * r.hp;
-    float R = 0.5f * (d1 * fast_rsq(d1) + d2 * fast_rsq(d2)) + 1.5e-3f;
-    float R2 = R * R;
+    // (r_g + r_p + 1.5e-3)^2 <= (d1 + d2 + 2 sqrt(d1 d2)) / 4 + 9.01e-3 for r_g + r_p < 3: one rsq, as in fast_cull
+    float d1 = r.wg * r.wg + r.hg * r.hg, d2 = r.wp * r.wp + r.hp * r.hp, prod = d1 * d2;
+    float R2 = 0.25f * (d1 + d2) + 0.5f * (prod * fast_rsq(prod)) + 9.01e-3f;
     float cosR_lb = fmaf(fmaf(fmaf(-1.0f / 720.0f, R2, 1.0f / 24.0f), R2, -0.5f), R2, 1.0f);
-    if (R < 3.0f && r.C < cosR_lb) return FAST_ZERO;
+    if (R2 < 8.9f && r.C < cosR_lb) return FAST_ZERO;
     return FAST_SURVIVOR;
 }
 
