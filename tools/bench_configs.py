@@ -15,10 +15,18 @@ from sph_retina_amd.losses import Sph2PobIoULoss  # noqa: E402
 from sph_retina_amd.bbox.nms import SphNMS  # noqa: E402
 
 
-def timeit(fn, warm=5, reps=30):
+def timeit(fn, warm=5, reps=30, settle_s=0.03):
+    """Seconds per call, HIP events around `reps` back-to-back calls.  After `warm` calls the function is repeated for
+    another `settle_s` seconds untimed: the clocks drop while the host prepares inputs and only recover after a few
+    thousand launches (a 14 us kernel measured right after an idle gap reads 32 us)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < settle_s:
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -193,6 +201,23 @@ def unbiased(n=1_000_000):
     return out
 
 
+def variants(n=1_000_000):
+    """Aligned IoU, 1 M uniform pairs, every operator of sphdet.iou that the kernels serve (us per call through the
+    Python boundary, back-to-back)."""
+    from sph_retina_amd import iou as I
+    out = {'config': 'aligned IoU operators, %d uniform pairs (us per call)' % n}
+    for dim in (4, 5):
+        a, b = boxes(n, 0, dim), boxes(n, 1, dim)
+        ops = [('sph2pob_standard_iou', I.sph2pob_standard_iou), ('sph2pob_efficient_iou', I.sph2pob_efficient_iou)]
+        if dim == 4:
+            ops += [('sph2pob_legacy_iou', I.sph2pob_legacy_iou), ('sph_iou', I.sph_iou), ('fov_iou', I.fov_iou)]
+        r = {}
+        for name, fn in ops:
+            r[name] = timeit(lambda: fn(a, b, is_aligned=True), warm=50, reps=300) * 1e6
+        out['bfov' if dim == 4 else 'rbfov'] = r
+    return out
+
+
 if __name__ == '__main__':
-    for fn in (config3, config4, coder, unbiased):
+    for fn in (config3, config4, coder, unbiased, variants):
         print(json.dumps(fn()), flush=True)
