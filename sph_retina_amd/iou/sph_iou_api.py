@@ -57,7 +57,8 @@ def _sph2pob_iou_auxiliary(bboxes1, bboxes2, variant, mode, is_aligned, calculat
         G.call('sph2pob_iou_pairwise_f32', b1.device, G.ptr(b1), ctypes.c_int64(rows), G.ptr(b2),
                ctypes.c_int64(cols), G.ptr(out), dim, G.VARIANTS[variant], mode_c, edge_c, angle_c,
                G.stream_of(b1))
-    return out if bboxes1.dtype == torch.float32 else out.to(bboxes1.dtype)
+    # fp64 / fp16 / bf16 boxes get their dtype back (computed in fp32); integer boxes get fp32 IoUs
+    return out if bboxes1.dtype == torch.float32 or not bboxes1.is_floating_point() else out.to(bboxes1.dtype)
 
 
 def sph_iou(bboxes1, bboxes2, mode='iou', is_aligned=False, calculator='diff'):
