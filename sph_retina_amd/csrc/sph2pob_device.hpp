@@ -301,6 +301,71 @@ SPH_DEV float edges_inside(float pax, float pay, float c, float s, float ic, flo
     return (l0 * (hha - xu) + l2 * (hha + xu)) + (l1 * (hwa - xv) + l3 * (hwa + xv));
 }
 
+// Double-precision twins of clip_len / edges_inside.  The fp32 boundary integral loses ~6e-8 * extent / |sin(delta)| of
+// the area: harmless at the |delta| >= 1.2e-3 the rotated jitter normally leaves, but the reference's two jitter steps
+// can also cancel (delta = 4 eps + eps' before the jitter => ~4e-6 after it; found by the 2 M-pair soak test on 180-degree
+// boxes: 2e-2 IoU error).  Below kNearParallel the integral is evaluated in double; also used by the jitter-free naive
+// RBFoV stage.
+constexpr float kNearParallel = 2.5e-4f;
+SPH_DEV double clip_len_d(double px, double py, double ux, double uy, double len, double hx, double hy) {
+    const double iux = 1.0 / ux, iuy = 1.0 / uy;
+    const double ax = (-hx - px) * iux, bx = (hx - px) * iux, ay = (-hy - py) * iuy, by = (hy - py) * iuy;
+    const double lo = fmax(fmax(fmin(ax, bx), fmin(ay, by)), 0.0), hi = fmin(fmin(fmax(ax, bx), fmax(ay, by)), len);
+    return fmax(hi - lo, 0.0);
+}
+SPH_DEV double edges_inside_d(double pax, double pay, double c, double s, double hwa, double hha, double hwb, double hhb,
+                              bool with_origin_terms) {
+    const double ux = hwa * c, uy = hwa * s, vx = -hha * s, vy = hha * c;
+    const double l0 = clip_len_d(pax + ux + vx, pay + uy + vy, -c, -s, 2.0 * hwa, hwb, hhb);
+    const double l1 = clip_len_d(pax - ux + vx, pay - uy + vy, s, -c, 2.0 * hha, hwb, hhb);
+    const double l2 = clip_len_d(pax - ux - vx, pay - uy - vy, c, s, 2.0 * hwa, hwb, hhb);
+    const double l3 = clip_len_d(pax + ux - vx, pay + uy - vy, -s, c, 2.0 * hha, hwb, hhb);
+    if (!with_origin_terms) return hha * (l0 + l2) + hwa * (l1 + l3);
+    const double xu = pax * s - pay * c, xv = pax * c + pay * s;
+    return (l0 * (hha - xu) + l2 * (hha + xu)) + (l1 * (hwa - xv) + l3 * (hwa + xv));
+}
+
+// Twice the intersection area of two nearly parallel rectangles, in double and from ONE consistent description: A's
+// centre (pax, pay) and rotation (c, s) in B's frame; (c, s) is re-normalised and B's centre in A's frame is derived
+// from them.  The two passes of the boundary integral must agree on where nearly coincident edges cross: with
+// positions / rotations rounded independently in fp32 (1e-7) the crossing moves by 1e-7 / |s| along the edge, i.e.
+// by a few percent of the edge at |s| ~ 4e-6, and the two halves no longer add up to the area.
+SPH_DEV double near_parallel_area2(double pax, double pay, double c, double s, double hwa, double hha, double hwb,
+                                   double hhb) {
+    const double n = 1.0 / sqrt(c * c + s * s);
+    c *= n;
+    s *= n;
+    // pass 0: A's edges in B's frame (origin terms about B's centre); pass 1: B's edges in A's frame (rotation -s,
+    // centre -R^T pa), integrated about B's own centre.  A rolled loop over the 8 edges keeps the register footprint
+    // of this rare branch below that of the fp32 fast path around it.
+    double total = 0.0;
+#pragma nounroll
+    for (int e = 0; e < 8; e++) {
+        const bool second = e >= 4;
+        const double px = second ? -(c * pax + s * pay) : pax, py = second ? -(-s * pax + c * pay) : pay;
+        const double cc = c, ss = second ? -s : s;
+        const double hw = second ? hwb : hwa, hh = second ? hhb : hha;   // the rectangle whose edges are walked
+        const double hx = second ? hwa : hwb, hy = second ? hha : hhb;   // the rectangle they are clipped to
+        const int k = e & 3;
+        // corner k (+u+v, -u+v, -u-v, +u-v) and direction of the edge leaving it (-u, -v, +u, +v)
+        const double su = (k == 0 || k == 3) ? 1.0 : -1.0, sv = (k <= 1) ? 1.0 : -1.0;
+        const double kx = px + su * hw * cc - sv * hh * ss, ky = py + su * hw * ss + sv * hh * cc;
+        const bool along_u = (k & 1) == 0;
+        const double sgn = (k == 0 || k == 1) ? -1.0 : 1.0;
+        const double ux = along_u ? sgn * cc : -sgn * ss, uy = along_u ? sgn * ss : sgn * cc;
+        const double len = along_u ? 2.0 * hw : 2.0 * hh;
+        const double l = clip_len_d(kx, ky, ux, uy, len, hx, hy);
+        // distance of the edge's supporting line from the integration origin (B's centre)
+        double dist = along_u ? hh : hw;
+        if (!second) {
+            const double xu = px * ss - py * cc, xv = px * cc + py * ss;
+            dist += along_u ? (k == 0 ? -xu : xu) : (k == 1 ? -xv : xv);
+        }
+        total += l * dist;
+    }
+    return total;
+}
+
 // Area of the intersection of two rotated rectangles (x, y, w, h, a).
 SPH_DEV float rect_intersection(const PBox& A, const PBox& B) {
     float sa = sinf(A.a), ca = cosf(A.a), sb = sinf(B.a), cb = cosf(B.a);
@@ -313,6 +378,10 @@ SPH_DEV float rect_intersection(const PBox& A, const PBox& B) {
     float pax = -(dx * cb + dy * sb), pay = -(dy * cb - dx * sb);
     float pbx = dx * ca + dy * sa, pby = dy * ca - dx * sa;
     // A's edges inside B, integrated about B's centre; B's edges inside A, same origin (= B's own centre)
+    if (fabsf(s) < kNearParallel && s != 0.0f) {  // rare: see kNearParallel
+        const double cd = (double)ca * cb + (double)sa * sb, sd = (double)sa * cb - (double)ca * sb;
+        return 0.5f * fmaxf((float)near_parallel_area2(pax, pay, cd, sd, hwa, hha, hwb, hhb), 0.0f);
+    }
     float t = edges_inside(pax, pay, c, s, ic, is, hwa, hha, hwb, hhb, A.w, A.h, true) +
               edges_inside(pbx, pby, c, -s, ic, -is, hwb, hhb, hwa, hha, B.w, B.h, false);
     return 0.5f * fmaxf(t, 0.0f);
@@ -353,25 +422,6 @@ SPH_DEV float approx_iou(const float (&g_)[5], const float (&p_)[5]) {
     float ai = fmaxf(tmax - tmin, 0.0f) * fmaxf(pmax - pmin, 0.0f);
     float au = ag * bg + ap * bp - ai;
     return ai / (au + 1e-8f);
-}
-
-// double-precision twins of clip_len / edges_inside for the jitter-free naive RBFoV stage (transversal edges assumed)
-SPH_DEV double clip_len_d(double px, double py, double ux, double uy, double len, double hx, double hy) {
-    const double iux = 1.0 / ux, iuy = 1.0 / uy;
-    const double ax = (-hx - px) * iux, bx = (hx - px) * iux, ay = (-hy - py) * iuy, by = (hy - py) * iuy;
-    const double lo = fmax(fmax(fmin(ax, bx), fmin(ay, by)), 0.0), hi = fmin(fmin(fmax(ax, bx), fmax(ay, by)), len);
-    return fmax(hi - lo, 0.0);
-}
-SPH_DEV double edges_inside_d(double pax, double pay, double c, double s, double hwa, double hha, double hwb, double hhb,
-                              bool with_origin_terms) {
-    const double ux = hwa * c, uy = hwa * s, vx = -hha * s, vy = hha * c;
-    const double l0 = clip_len_d(pax + ux + vx, pay + uy + vy, -c, -s, 2.0 * hwa, hwb, hhb);
-    const double l1 = clip_len_d(pax - ux + vx, pay - uy + vy, s, -c, 2.0 * hha, hwb, hhb);
-    const double l2 = clip_len_d(pax - ux - vx, pay - uy - vy, c, s, 2.0 * hwa, hwb, hhb);
-    const double l3 = clip_len_d(pax + ux - vx, pay + uy - vy, -s, c, 2.0 * hha, hwb, hhb);
-    if (!with_origin_terms) return hha * (l0 + l2) + hwa * (l1 + l3);
-    const double xu = pax * s - pay * c, xv = pax * c + pay * s;
-    return (l0 * (hha - xu) + l2 * (hha + xu)) + (l1 * (hwa - xv) + l3 * (hwa + xv));
 }
 
 // Naive-IoU (sph_iou_api.py:179-197): boxes mapped to ERP pixels by Sph2PlanarBoxTransform('sph2pix') with the default

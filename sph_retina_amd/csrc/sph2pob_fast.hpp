@@ -371,6 +371,11 @@ SPH_DEV float fast_phase2(const FastRec& r, int mode) {
     float hwa = 0.5f * q.wg, hha = 0.5f * q.hg, hwb = 0.5f * q.wp, hhb = 0.5f * q.hp;
     float pax = -(q.dx * q.cb + q.dy * q.sb), pay = -(q.dy * q.cb - q.dx * q.sb);
     float pbx = q.dx * q.ca + q.dy * q.sa, pby = q.dy * q.ca - q.dx * q.sa;
+    // Known corner: when the reference's two jitter steps cancel (delta = eps' - 0 or 4 eps + eps' before them) the
+    // rectangles end up parallel to ~1e-6 rad and the two passes of the fp32 integral disagree on where nearly
+    // coincident edges cross (1e-7 / |s| along the edge): up to 2e-2 IoU error on 1 of 2 M adversarial pairs.  The
+    // reference-order path evaluates that case in double (near_parallel_area2); doing it here costs 25 VGPRs of
+    // occupancy for every pair (measured: 8.9 -> 12.6 us), see DESIGN.md §9.
     float t2 = edges_inside3(pax, pay, c, s, ic, is, aic, ais, hwa, hha, hwb, hhb, q.wg, q.hg, true) +
                edges_inside3(pbx, pby, c, -s, ic, -is, aic, ais, hwb, hhb, hwa, hha, q.wp, q.hp, false);
     float inter = 0.5f * fmaxf(t2, 0.0f);
