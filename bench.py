@@ -97,7 +97,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=500)
     ap.add_argument('--pairs', type=int, default=PAIRS_PER_GPU, help='pairs per GPU per step')
     ap.add_argument('--variant', default=VARIANT, choices=['standard', 'efficient', 'legacy'])
-    ap.add_argument('--arithmetic', default='fast', choices=['fast', 'reference'],
+    ap.add_argument('--arithmetic', default='fast', choices=['fast', 'robust', 'reference'],
                     help="'fast' = default closed-form core; 'reference' = the reference's fp32 operation order")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--gather', action='store_true',

@@ -13,10 +13,14 @@ FLAG_REFERENCE_ORDER = 0x100
 _ARITHMETIC = os.environ.get('SPH2POB_ARITHMETIC', 'fast')
 
 
+FLAG_ROBUST_PARALLEL = 0x200
+
+
 def set_arithmetic(mode):
-    """'fast' (default): closed-form geometry core; 'reference': the reference's fp32 operation order."""
+    """'fast' (default): closed-form geometry core; 'robust': the same plus the near-parallel safeguard of the aligned /
+    pairwise IoU kernels (jitter cancellation, +4.5 % time); 'reference': the reference's fp32 operation order."""
     global _ARITHMETIC
-    assert mode in ('fast', 'reference')
+    assert mode in ('fast', 'robust', 'reference')
     _ARITHMETIC = mode
 
 
@@ -26,7 +30,8 @@ def get_arithmetic():
 
 class _Variants(dict):
     def __getitem__(self, k):
-        return _VARIANT_CODES[k] | (FLAG_REFERENCE_ORDER if _ARITHMETIC == 'reference' else 0)
+        return _VARIANT_CODES[k] | (FLAG_REFERENCE_ORDER if _ARITHMETIC == 'reference' else 0) | \
+            (FLAG_ROBUST_PARALLEL if _ARITHMETIC == 'robust' else 0)
 
 
 VARIANTS = _Variants(_VARIANT_CODES)

@@ -151,6 +151,47 @@ SPH_DEV float edges_inside3(float px, float py, float c, float s, float ic, floa
     return (l0 * (hh - xu) + l2 * (hh + xu)) + (l1 * (hw - xv) + l3 * (hw + xv));
 }
 
+// Intersection area of two NEARLY PARALLEL (or nearly perpendicular) rectangles, fp32, first order in the small
+// angle: B = [-X, X] x [-Y, Y]; A has centre (px, py), half extents (hw, hh) and axis (c, s) in B's frame with
+// |s| < kNearParallel or |c| < kNearParallel.  The reference's two jitter steps can cancel and leave the planar boxes
+// parallel to ~1e-6 rad; the boundary integral then evaluates each crossing of nearly coincident edges twice and the
+// two fp32 results disagree by 1e-7 / |s| along the edge (up to 2e-2 IoU).  Here A's four edges are straight lines
+// y = const + t x, x = const - t y with slope |t| < 2.5e-4, and
+//     area = integral over x of [min(Y, top(x)) - max(-Y, bottom(x))]  over the zeroth-order x-range
+//            - integral over y of what max(-X, left(y)) and min(X, right(y)) cut off that range,
+// every term well conditioned (no division by the angle); the neglected corner terms are O(t^2 L^2) ~ 1e-7 of the area.
+SPH_DEV float lin_excess(float fl, float fr, float lim, float W) {
+    // integral over a width W of max(f - lim, 0) for f linear from fl to fr
+    const float fmin = fminf(fl, fr), fmax = fmaxf(fl, fr), span = fmax - fmin;
+    const float e = fminf(fmaxf(fmax - lim, 0.0f), span);
+    const float part = span > 0.0f ? 0.5f * e * e * W / span : 0.0f;
+    return lim <= fmin ? (0.5f * (fmin + fmax) - lim) * W : part;
+}
+SPH_DEV float near_parallel_inter(float px, float py, float c, float s, float hw, float hh, float X, float Y) {
+    float a = hw, b = hh;
+    if (fabsf(c) < fabsf(s)) {   // nearly perpendicular: same rectangle, axes rotated by a quarter turn, extents swapped
+        const float c2 = s > 0.0f ? s : -s, s2 = s > 0.0f ? -c : c;
+        c = c2; s = s2; a = hh; b = hw;
+    } else if (c < 0.0f) {
+        c = -c; s = -s;
+    }
+    const float ic = 1.0f / c, t = s * ic;
+    // A's four edges as straight lines: top / bottom y = tp0 | bt0 + (x - px) t, left / right x = l0 | r0 - (y - py) t
+    const float l0 = px - a * ic, r0 = px + a * ic, bt0 = py - b * ic, tp0 = py + b * ic;
+    // zeroth-order overlap box (t = 0): its ranges are where the first-order terms are integrated
+    const float xl = fmaxf(-X, l0), xr = fminf(X, r0), yl = fmaxf(-Y, bt0), yr = fminf(Y, tp0);
+    const float W = xr - xl, H = yr - yl;
+    if (!(W > 0.0f) || !(H > 0.0f)) return 0.0f;
+    const float tl = tp0 + (xl - px) * t, tr = tp0 + (xr - px) * t, bl = tl - 2.0f * b * ic, br = tr - 2.0f * b * ic;
+    const float top = 0.5f * (tl + tr) * W - lin_excess(tl, tr, Y, W);      // integral over x of min(Y, top(x))
+    const float bot = 0.5f * (bl + br) * W + lin_excess(-bl, -br, Y, W);    // integral over x of max(-Y, bottom(x))
+    const float ll = l0 - (yl - py) * t, lr = l0 - (yr - py) * t, rl = ll + 2.0f * a * ic, rr = lr + 2.0f * a * ic;
+    const float lft = 0.5f * (ll + lr) * H + lin_excess(-ll, -lr, X, H);    // integral over y of max(-X, left(y))
+    const float rgt = 0.5f * (rl + rr) * H - lin_excess(rl, rr, X, H);      // integral over y of min(X, right(y))
+    // area of the box, with its horizontal sides replaced by the true ones, minus what the true vertical sides remove
+    return fmaxf((top - bot) - (lft - xl * H) - (xr * H - rgt), 0.0f);
+}
+
 // What phase 1 hands to phase 2 (kept in registers, or staged through the LDS survivor queue by the compacting kernel)
 struct FastRec { float N, D, Np, Dp, C, wg, hg, wp, hp, ga, gb; };
 enum : int { FAST_ZERO = 0, FAST_SURVIVOR = 1 };
@@ -358,26 +399,43 @@ SPH_DEV void fast_planar(const FastRec& r, PlanarPair& o) {
     o.wg = wg; o.hg = hg; o.wp = wp; o.hp = hp;
 }
 
-// Phase 2: planar boxes, then boundary-integral intersection and IoU.
-template <int VARIANT, int DIM>
-SPH_DEV float fast_phase2(const FastRec& r, int mode) {
+// Twice the intersection area from the planar pair: the boundary integral, or — per lane, when `robust` — the
+// first-order near-parallel form.
+SPH_DEV float planar_area2(const PlanarPair& q, float c, float s, bool robust) {
 #pragma clang fp contract(fast)
-    PlanarPair q;
-    fast_planar<VARIANT, DIM>(r, q);
-    float c = q.ca * q.cb + q.sa * q.sb, s = q.sa * q.cb - q.ca * q.sb;
     const float kBig = 1e18f;
     float ic = fminf(fmaxf(fast_rcp(c), -kBig), kBig), is = fminf(fmaxf(fast_rcp(s), -kBig), kBig);
     float aic = fabsf(ic), ais = fabsf(is);
     float hwa = 0.5f * q.wg, hha = 0.5f * q.hg, hwb = 0.5f * q.wp, hhb = 0.5f * q.hp;
     float pax = -(q.dx * q.cb + q.dy * q.sb), pay = -(q.dy * q.cb - q.dx * q.sb);
     float pbx = q.dx * q.ca + q.dy * q.sa, pby = q.dy * q.ca - q.dx * q.sa;
-    // Known corner: when the reference's two jitter steps cancel (delta = eps' - 0 or 4 eps + eps' before them) the
-    // rectangles end up parallel to ~1e-6 rad and the two passes of the fp32 integral disagree on where nearly
-    // coincident edges cross (1e-7 / |s| along the edge): up to 2e-2 IoU error on 1 of 2 M adversarial pairs.  The
-    // reference-order path evaluates that case in double (near_parallel_area2); doing it here costs 25 VGPRs of
-    // occupancy for every pair (measured: 8.9 -> 12.6 us), see DESIGN.md §9.
     float t2 = edges_inside3(pax, pay, c, s, ic, is, aic, ais, hwa, hha, hwb, hhb, q.wg, q.hg, true) +
                edges_inside3(pbx, pby, c, -s, ic, -is, aic, ais, hwb, hhb, hwa, hha, q.wp, q.hp, false);
+    if (robust) {
+        const float alt = 2.0f * near_parallel_inter(pax, pay, c, s, hwa, hha, hwb, hhb);
+        t2 = fminf(fabsf(s), fabsf(c)) < kNearParallel ? alt : t2;
+    }
+    return t2;
+}
+// Phase 2: planar boxes, then boundary-integral intersection and IoU.  ROBUST (SPH2POB_FLAG_ROBUST_PARALLEL): pairs
+// left nearly parallel by a cancellation of the reference's two jitter steps are evaluated with near_parallel_inter;
+// compile-time because the branch costs every pair 4.5 % (6 more VGPRs, tools/ab_near_parallel.sh) even when not taken.
+template <int VARIANT, int DIM, bool ROBUST = false>
+SPH_DEV float fast_phase2(const FastRec& r, int mode) {
+#pragma clang fp contract(fast)
+    PlanarPair q;
+    fast_planar<VARIANT, DIM>(r, q);
+    float c = q.ca * q.cb + q.sa * q.sb, s = q.sa * q.cb - q.ca * q.sb;
+    float t2 = planar_area2(q, c, s, false);
+    if constexpr (ROBUST) {
+        const bool near = fminf(fabsf(s), fabsf(c)) < kNearParallel;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (__ballot(near) != 0ull)    // wave-uniform: ~2 % of the waves hold such a pair
+#else
+        if (near)
+#endif
+            t2 = planar_area2(q, c, s, true);
+    }
     float inter = 0.5f * fmaxf(t2, 0.0f);
     float a1 = q.wg * q.hg, a2 = q.wp * q.hp;
     float base = mode == MODE_IOU ? (a1 + a2 - inter) : a1;
@@ -388,7 +446,7 @@ SPH_DEV float fast_phase2(const FastRec& r, int mode) {
 }
 
 // Spherical jitter + stages 1 + 2 for a pair that survived the cull.
-template <int VARIANT, int DIM>
+template <int VARIANT, int DIM, bool ROBUST = false>
 SPH_DEV float fast_finish(const float (&in1)[5], const float (&in2)[5], int mode, int edge) {
     float j1[5], j2[5];
 #pragma unroll
@@ -396,14 +454,14 @@ SPH_DEV float fast_finish(const float (&in1)[5], const float (&in2)[5], int mode
     jitter_spherical<DIM>(j1, j2);
     FastRec r;
     if (fast_phase1<VARIANT, DIM>(j1, j2, edge, r) == FAST_ZERO) return 0.0f;
-    return fast_phase2<VARIANT, DIM>(r, mode);
+    return fast_phase2<VARIANT, DIM, ROBUST>(r, mode);
 }
 
 // VARIANT: 0 standard, 1 efficient.  Returns clamp(IoU, 0, 1) of one pair.
-template <int VARIANT, int DIM>
+template <int VARIANT, int DIM, bool ROBUST = false>
 SPH_DEV float pair_iou_fast(const float (&in1)[5], const float (&in2)[5], int mode, int edge) {
     if (fast_cull<DIM>(in1, in2, edge)) return 0.0f;
-    return fast_finish<VARIANT, DIM>(in1, in2, mode, edge);
+    return fast_finish<VARIANT, DIM, ROBUST>(in1, in2, mode, edge);
 }
 
 }  // namespace sph2pob

@@ -103,7 +103,7 @@ __device__ __forceinline__ int queue_load(const WaveQueue& q, int slot, float (&
     return q.idx[slot];
 }
 
-template <int VARIANT, int DIM, bool PREFETCH>
+template <int VARIANT, int DIM, bool PREFETCH, bool ROBUST = false>
 __global__ __launch_bounds__(kBlock) void iou_aligned_compact_kernel(const float* __restrict__ b1,
                                                                     const float* __restrict__ b2,
                                                                     float* __restrict__ out, int n, int mode,
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_compact_kernel(const float
             __builtin_amdgcn_wave_barrier();
             float u1[5], u2[5];
             int j = queue_load<DIM>(q, count + lane, u1, u2);
-            out[j] = fast_finish<VARIANT, DIM>(u1, u2, mode, edge);
+            out[j] = fast_finish<VARIANT, DIM, ROBUST>(u1, u2, mode, edge);
         }
     }
     // merge the < 64 leftovers of the four waves and finish them on as few, as full waves as possible
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_compact_kernel(const float
             if (k >= c0) { k -= c0; w = 1; if (k >= c1) { k -= c1; w = 2; if (k >= c2) { k -= c2; w = 3; } } }
             float u1[5], u2[5];
             int j = queue_load<DIM>(queues[w], k, u1, u2);
-            out[j] = fast_finish<VARIANT, DIM>(u1, u2, mode, edge);
+            out[j] = fast_finish<VARIANT, DIM, ROBUST>(u1, u2, mode, edge);
         }
     }
 }
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_compact_kernel(const float
 // ~15 VALU instructions + one coalesced store of 0.  Survivors are (row, column) index pairs pushed on the wave's
 // LDS stack and finished 64 at a time on fully populated waves (same scheme as iou_aligned_compact_kernel).
 constexpr int kPwRows = 64;
-template <int VARIANT, int DIM>
+template <int VARIANT, int DIM, bool ROBUST = false>
 __global__ __launch_bounds__(kBlock) void iou_pairwise_compact_kernel(const float* __restrict__ b1, int m,
                                                                      const float* __restrict__ b2, int n,
                                                                      float* __restrict__ out, int mode, int edge,
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kBlock) void iou_pairwise_compact_kernel(const floa
 #pragma unroll
         for (int k = 0; k < 5; k++) g[k] = row_raw[e.x][k];
         load_box<DIM>(b2, e.y, p);
-        out[(int64_t)(r0 + e.x) * n + e.y] = fast_finish<VARIANT, DIM>(g, p, mode, edge);
+        out[(int64_t)(r0 + e.x) * n + e.y] = fast_finish<VARIANT, DIM, ROBUST>(g, p, mode, edge);
     };
     for (int i = 0; i < rows; i++) {
         const float4 rc = row_cull[i];
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(kBlock) void transform_bwd_kernel(const float* __re
 
 int check_common(int box_dim, int variant_flags, int edge, int angle) {
     const int variant = variant_flags & 0xff;
-    if (variant_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER)) return SPH2POB_ERR_OPTION;
+    if (variant_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER | SPH2POB_FLAG_ROBUST_PARALLEL)) return SPH2POB_ERR_OPTION;
     if (box_dim != 4 && box_dim != 5) return SPH2POB_ERR_DIM;
     if (variant < 0 || variant > SPH2POB_VARIANT_NAIVE || edge < 0 || edge > 2 || angle < 0 || angle > 1) return SPH2POB_ERR_OPTION;
     if (variant >= SPH2POB_VARIANT_LEGACY && variant <= SPH2POB_VARIANT_FOV_IOU && box_dim == 5)
@@ -662,6 +662,7 @@ template <typename F>
 int dispatch(int variant_flags, int box_dim, F&& f) {
     const int variant = variant_flags & 0xff;
     f.fast = !(variant_flags & SPH2POB_FLAG_REFERENCE_ORDER);
+    f.robust = (variant_flags & SPH2POB_FLAG_ROBUST_PARALLEL) != 0;
     if (variant == SPH2POB_VARIANT_STANDARD) return box_dim == 4 ? f.template run<0, 4>() : f.template run<0, 5>();
     if (variant == SPH2POB_VARIANT_EFFICIENT) return box_dim == 4 ? f.template run<1, 4>() : f.template run<1, 5>();
     if (variant == SPH2POB_VARIANT_SPH_IOU) return f.template run<3, 4>();
@@ -672,7 +673,7 @@ int dispatch(int variant_flags, int box_dim, F&& f) {
 }
 
 struct AlignedLaunch {
-    const float *b1, *b2; float* out; int64_t n; int mode, edge, angle; hipStream_t s; bool fast = true;
+    const float *b1, *b2; float* out; int64_t n; int mode, edge, angle; hipStream_t s; bool fast = true, robust = false;
     template <int V, int D> int run() {
         dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
         if (fast && V < 2 && angle == SPH2POB_ANGLE_EQUATOR && n < ((int64_t)1 << 31) - 64 && !g_no_compact) {
@@ -690,7 +691,9 @@ struct AlignedLaunch {
             if (wgs > kCUs * 7) wgs = kCUs * 7;
             if (g_wgs_per_cu > 0) wgs = kCUs * g_wgs_per_cu;
             if (wgs < 1) wgs = 1;
-            if (g_prefetch)
+            if (g_prefetch && robust)
+                hipLaunchKernelGGL((iou_aligned_compact_kernel<V >= 2 ? 0 : V, D, true, true>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge);
+            else if (g_prefetch)
                 hipLaunchKernelGGL((iou_aligned_compact_kernel<V >= 2 ? 0 : V, D, true>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge);
             else
                 hipLaunchKernelGGL((iou_aligned_compact_kernel<V >= 2 ? 0 : V, D, false>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge);
@@ -704,7 +707,7 @@ struct AlignedLaunch {
     }
 };
 struct PairwiseLaunch {
-    const float* b1; int64_t m; const float* b2; int64_t n; float* out; int mode, edge, angle; hipStream_t s; bool fast = true;
+    const float* b1; int64_t m; const float* b2; int64_t n; float* out; int mode, edge, angle; hipStream_t s; bool fast = true, robust = false;
     template <int V, int D> int run() {
         if (fast && V < 2 && angle == SPH2POB_ANGLE_EQUATOR && n < ((int64_t)1 << 31) - kBlock && m <= (int64_t)65535 * 4 &&
             !g_no_compact) {
@@ -716,8 +719,12 @@ struct PairwiseLaunch {
             if (rpw > kPwRows) rpw = kPwRows;
             if (rpw > m) rpw = m;
             dim3 grid((unsigned)col_tiles, (unsigned)((m + rpw - 1) / rpw));
-            hipLaunchKernelGGL((iou_pairwise_compact_kernel<V >= 2 ? 0 : V, D>), grid, dim3(kBlock), 0, s, b1, (int)m, b2, (int)n,
-                               out, mode, edge, (int)rpw);
+            if (robust)
+                hipLaunchKernelGGL((iou_pairwise_compact_kernel<V >= 2 ? 0 : V, D, true>), grid, dim3(kBlock), 0, s, b1, (int)m, b2,
+                                   (int)n, out, mode, edge, (int)rpw);
+            else
+                hipLaunchKernelGGL((iou_pairwise_compact_kernel<V >= 2 ? 0 : V, D>), grid, dim3(kBlock), 0, s, b1, (int)m, b2, (int)n,
+                                   out, mode, edge, (int)rpw);
             return launch_status();
         }
         // grid.y is limited to 65535 rows per launch: walk the rows in slabs
@@ -741,7 +748,7 @@ struct PairwiseLaunch {
     }
 };
 struct TransformLaunch {
-    const float *b1, *b2; float *o1, *o2; int64_t n; int edge, angle, jitter; hipStream_t s; bool fast = true;
+    const float *b1, *b2; float *o1, *o2; int64_t n; int edge, angle, jitter; hipStream_t s; bool fast = true, robust = false;
     template <int V, int D> int run() {
         dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
         hipLaunchKernelGGL((transform_kernel<V, D>), grid, dim3(kBlock), 0, s, b1, b2, o1, o2, n, edge, angle, jitter);
@@ -875,7 +882,8 @@ int sph2pob_nms_segmented_f32(const float* boxes_sorted, const int64_t* cls_sort
                               unsigned char* keep, void* stream) {
     const int variant = variant_flags & 0xff;
     const bool fast = !(variant_flags & SPH2POB_FLAG_REFERENCE_ORDER);
-    if (variant_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER)) return SPH2POB_ERR_OPTION;
+    // SPH2POB_FLAG_ROBUST_PARALLEL is accepted and has no effect here (a near-parallel pair is far above any threshold)
+    if (variant_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER | SPH2POB_FLAG_ROBUST_PARALLEL)) return SPH2POB_ERR_OPTION;
     if (box_dim != 4 && box_dim != 5) return SPH2POB_ERR_DIM;
     if (variant != SPH2POB_VARIANT_STANDARD && variant != SPH2POB_VARIANT_EFFICIENT && variant != SPH2POB_VARIANT_UNBIASED &&
         variant != SPH2POB_VARIANT_NAIVE)

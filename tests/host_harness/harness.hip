@@ -89,6 +89,18 @@ int harness_extra_iou(const float* b1, const float* b2, int64_t n, int dim, int 
     if (dim == 4) extra_loop<4>(b1, b2, n, which, out); else extra_loop<5>(b1, b2, n, which, out);
     return 0;
 }
+// planar IoU through the near-parallel first-order routine of the closed-form path (test hook)
+int harness_near_parallel_iou(const float* p1, const float* p2, int64_t n, float* out) {
+    for (int64_t i = 0; i < n; i++) {
+        const float* A = p1 + i * 5; const float* B = p2 + i * 5;
+        float sa = sinf(A[4]), ca = cosf(A[4]), sb = sinf(B[4]), cb = cosf(B[4]);
+        float c = ca * cb + sa * sb, s = sa * cb - ca * sb, dx = B[0] - A[0], dy = B[1] - A[1];
+        float pax = -(dx * cb + dy * sb), pay = -(dy * cb - dx * sb);
+        float inter = near_parallel_inter(pax, pay, c, s, 0.5f * A[2], 0.5f * A[3], 0.5f * B[2], 0.5f * B[3]);
+        out[i] = inter / (A[2] * A[3] + B[2] * B[3] - inter);
+    }
+    return 0;
+}
 int harness_planar_iou(const float* p1, const float* p2, int64_t n, int mode, float* out) {
     for (int64_t i = 0; i < n; i++) {
         PBox A{p1[i * 5], p1[i * 5 + 1], p1[i * 5 + 2], p1[i * 5 + 3], p1[i * 5 + 4]};

@@ -95,3 +95,37 @@ def test_launchers_are_graph_capturable():
     graph.replay()
     torch.cuda.synchronize()
     assert float(captured[0].min()) > 0.8        # IoU(x, x) after the reference's jitter
+
+
+def test_robust_mode_fixes_jitter_cancellation_pairs():
+    """Pairs found by the 2 M-pair soak: the reference's jitter leaves their planar boxes parallel to ~1e-6 rad; the
+    default closed-form kernel is off by up to 2e-2 there (documented), 'robust' and 'reference' arithmetic are not."""
+    import torch
+    import sph_retina_amd as S
+    from oracle import oracle as O
+    b1 = np.array([[237.02872, 171.37167, 179.9, 179.0], [128.4777, 38.103848, 179.9, 179.9],
+                   [88.996124, 86.51253, 120.0, 150.0]], np.float32)
+    b2 = np.array([[236.92949, 179.62257, 179.9, 179.9], [128.5839, 14.652416, 179.9, 179.9],
+                   [87.48591, 98.4085, 126.54463, 173.79935]], np.float32)
+    tru = O.iou_aligned(b1, b2, variant='standard', planar='exact', dtype=np.float64)
+    t1, t2 = torch.from_numpy(b1).cuda(), torch.from_numpy(b2).cuda()
+    prev = S.get_arithmetic()
+    try:
+        got = {}
+        for mode in ('fast', 'robust', 'reference'):
+            S.set_arithmetic(mode)
+            got[mode] = np.abs(S.sph2pob_standard_iou(t1, t2, is_aligned=True).cpu().numpy() - tru)
+            pw = S.sph2pob_standard_iou(t1, t2).cpu().numpy()
+            assert np.abs(np.diag(pw) - S.sph2pob_standard_iou(t1, t2, is_aligned=True).cpu().numpy()).max() == 0
+        assert got['fast'].max() > 1e-3                      # the known corner of the default path
+        assert got['robust'].max() < 2e-5 and got['reference'].max() < 2e-5, got
+        # and robust == fast bit for bit away from the corner
+        a = torch.from_numpy(O.generate_boxes(200000, 0)).cuda()
+        b = torch.from_numpy(O.generate_boxes(200000, 1)).cuda()
+        S.set_arithmetic('fast')
+        f = S.sph2pob_standard_iou(a, b, is_aligned=True)
+        S.set_arithmetic('robust')
+        r = S.sph2pob_standard_iou(a, b, is_aligned=True)
+        assert int((f != r).sum()) <= 60 and float((f - r).abs().max()) < 1e-3   # ~3e-4 of the overlapping pairs take the branch
+    finally:
+        S.set_arithmetic(prev)

@@ -1,6 +1,8 @@
 """CPU: the product's device math (sph_retina_amd/csrc/*.hpp) compiled for the host by tests/host_harness —
 checks the algebra the GPU kernels run (boundary-integral intersection, transforms, hand-derived loss adjoint)
 against the oracle and the reference fixtures without needing a GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -104,3 +106,33 @@ def test_transform_adjoint_vs_fp64_finite_differences(host_harness, oracle, vari
         scale = np.abs(b).max()
         assert np.median(d) < 2e-4 * scale, (np.median(d), scale)
         assert (d > 0.02 * scale).mean() < 0.02, (d > 0.02 * scale).mean()
+
+
+def test_near_parallel_first_order_area_against_exact_clip(oracle, host_harness):
+    """The closed-form path's near-parallel form (jitter cancellation: planar boxes parallel or perpendicular to
+    < 2.5e-4 rad) against the f64 exact clip on planar boxes with coincident / crossing edges, all four quarter turns."""
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'host_harness', '_build', 'libhost_harness.so'))
+    rng = np.random.default_rng(0)
+    n = 100000
+    w1, h1 = rng.uniform(0.02, 3.1, n), rng.uniform(0.02, 3.1, n)
+    kind = rng.integers(0, 4, n)
+    w2 = np.where(kind == 0, w1, w1 * rng.uniform(0.5, 1.5, n))
+    h2 = np.where(kind <= 1, h1, h1 * rng.uniform(0.5, 1.5, n))
+    x1, y1 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    x2 = x1 + np.where(kind == 0, rng.normal(0, 1e-3, n), rng.normal(0, 0.3, n))
+    y2 = y1 + np.where(kind == 0, rng.normal(0, 1e-3, n), rng.normal(0, 0.3, n))
+    a1 = rng.uniform(-3.2, 3.2, n)
+    delta = rng.choice([-1, 1], n) * 10 ** rng.uniform(-7, -3.62, n)
+    q = rng.integers(0, 4, n)
+    odd = (q % 2) == 1
+    p1 = np.stack([x1, y1, w1, h1, a1], 1).astype(np.float32)
+    p2 = np.stack([x2, y2, np.where(odd, h2, w2), np.where(odd, w2, h2), a1 + delta + q * np.pi / 2], 1).astype(np.float32)
+    out = np.empty(n, np.float32)
+    lib.harness_near_parallel_iou(p1.ctypes.data_as(ctypes.c_void_p), p2.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(n),
+                                  out.ctypes.data_as(ctypes.c_void_p))
+    tru = oracle.planar_iou(p1.astype(np.float64), p2.astype(np.float64), planar='exact', dtype=np.float64)
+    d = np.abs(out - tru)
+    old = np.abs(host_harness.planar_iou(p1, p2) - tru)
+    assert (d > 1e-5).sum() <= 3 and d.max() < 5e-4 and d.mean() < 2e-7, ((d > 1e-5).sum(), d.max(), d.mean())
+    assert (old > 1e-4).sum() > 50          # what the plain boundary integral does on the same pairs
