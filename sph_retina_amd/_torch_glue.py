@@ -11,6 +11,8 @@ import os
 _VARIANT_CODES = {'standard': 0, 'efficient': 1, 'legacy': 2, 'sph_iou': 3, 'fov_iou': 4, 'unbiased': 5, 'naive': 6}
 FLAG_REFERENCE_ORDER = 0x100
 _ARITHMETIC = os.environ.get('SPH2POB_ARITHMETIC', 'fast')
+if _ARITHMETIC not in ('fast', 'robust', 'reference'):
+    raise ValueError(f"SPH2POB_ARITHMETIC must be 'fast', 'robust' or 'reference', got {_ARITHMETIC!r}")
 
 
 FLAG_ROBUST_PARALLEL = 0x200
