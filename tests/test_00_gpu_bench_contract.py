@@ -1,0 +1,56 @@
+"""GPU: bench.py prints ONE JSON line with the keys the driver's contract names (plus roofline and cpu_baseline), both
+as a plain process and under torch.distributed.run with one rank (the RCCL code path).
+
+The file sorts first on purpose: bench.py is started as a child process, and a process that has already initialised
+the GPU must not fork + exec on this pool — so these tests run before any other test touches the device and skip
+themselves if the device is already initialised in this process."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ['metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+        'dtype', 'data', 'config', 'roofline']
+
+
+def run(cmd):
+    import torch
+    if torch.cuda.is_initialized():
+        pytest.skip('the GPU is already initialised in this process: not starting child processes from it')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def check(d, steps, warmup):
+    for k in KEYS:
+        assert k in d, k
+    assert d['unit'] == 'pairs/s' and d['n_gpus'] == 1 and d['steps'] == steps and d['warmup'] == warmup
+    assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None and d['dtype'] == 'f32'
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0.05 < r['frac'] < 1.0
+    assert abs(d['value'] - 1_000_000 / (d['ms_per_step'] * 1e-3)) < 1e-3 * d['value']
+    assert 1e10 < d['value'] < 5e11
+
+
+def test_bench_single_process_contract():
+    d = run([sys.executable, 'bench.py', '--steps', '200', '--warmup', '20'])
+    check(d, 200, 20)
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['unit'] == 'pairs/s' and c['cores'] >= 1 and c['value'] > 1e5 and 'sample' in c
+
+
+def test_bench_under_torch_distributed_run_one_rank():
+    d = run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+             '--master-port', '29577', 'bench.py', '--gpus', '1', '--steps', '100', '--warmup', '10', '--force-dist',
+             '--no-cpu-baseline'])
+    check(d, 100, 10)
