@@ -111,6 +111,11 @@ def main():
     from sph_retina_amd import _lib, _torch_glue as G
     if rank_env() == 0:
         _lib.build()   # no-op when sph_retina_amd/lib/libsph2pob_hip.so is up to date
+        if not args.no_cpu_baseline:
+            # the CPU-baseline leg's checker is built here, BEFORE this process initialises the GPU: on this pool a
+            # process must not fork + exec (make / gcc) once it has touched the device
+            from oracle import oracle as _O
+            _O.build()
     else:
         for _ in range(600):   # other ranks wait for rank 0's build instead of racing it
             if not _lib._stale():
