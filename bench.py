@@ -67,7 +67,7 @@ def cpu_baseline(n_sample=1_000_000):
     cores = min(O.max_threads(), len(os.sched_getaffinity(0)))
     O.iou_aligned(b1[:20000], b2[:20000], variant=VARIANT, planar='mmcv', nthreads=cores)  # spin up the pool
     reps, t_total = 0, 0.0
-    while t_total < 10.0 and reps < 64:   # ~10 s of CPU work, bounded
+    while t_total < 10.0 and reps < 400:   # ~10 s of CPU work, bounded
         t0 = time.perf_counter()
         O.iou_aligned(b1, b2, variant=VARIANT, planar='mmcv', nthreads=cores)
         t_total += time.perf_counter() - t0
