@@ -89,10 +89,16 @@ def build(force=False, verbose=False):
     if not os.path.exists(hipcc):
         raise Sph2PobLibraryError('hipcc not found: cannot build libsph2pob_hip.so')
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc] + HIPCC_FLAGS + ['-o', LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    tmp = f'{LIB_PATH}.tmp.{os.getpid()}'   # built aside and renamed: other ranks / processes never see a partial file
+    cmd = [hipcc] + HIPCC_FLAGS + ['-o', tmp] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(' '.join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+    try:
+        subprocess.check_call(cmd, cwd=CSRC)
+        os.replace(tmp, LIB_PATH)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB_PATH
 
 
