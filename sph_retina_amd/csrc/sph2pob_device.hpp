@@ -49,6 +49,21 @@ SPH_DEV float clampf(float x, float lo, float hi) {
 #endif
 }
 
+// NaN-propagating min / max (IEEE-754-2019 minimum / maximum: one v_minimum3_f32 / v_maximum3_f32 on gfx950, and no
+// v_max x, x canonicalisation in front of them).  torch.clamp propagates NaN and maps +-inf to the bound; fminf / fmaxf
+// and v_med3_f32 return the non-NaN operand, which would turn a NaN box of a diverged network into a valid-looking one.
+SPH_DEV float min_nan(float a, float b) { return __builtin_elementwise_minimum(a, b); }
+SPH_DEV float max_nan(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+// NaN iff any coordinate of the pair is NaN (+-inf stays inf: the reference's clamps make it finite; an infinite gamma,
+// which the reference never clamps for bboxes1 and whose sine is NaN, counts as NaN)
+template <int DIM>
+SPH_DEV bool pair_has_nan(const float (&a)[5], const float (&b)[5]) {
+    float m = max_nan(max_nan(a[0], a[1]), max_nan(a[2], a[3]));
+    m = max_nan(m, max_nan(max_nan(b[0], b[1]), max_nan(b[2], b[3])));
+    if (DIM == 5) m = max_nan(m, max_nan(a[4] - a[4], b[4] - b[4]));   // inf - inf = NaN
+    return m != m;
+}
+
 SPH_DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
 SPH_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
 SPH_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
@@ -471,6 +486,7 @@ SPH_DEV float naive_iou(const float (&b1)[5], const float (&b2)[5]) {
 // _sph2pob_iou_auxiliary for one pair — sph_iou_api.py:48-86
 template <int VARIANT, int DIM>
 SPH_DEV float pair_iou(const float (&in1)[5], const float (&in2)[5], int mode, int edge, int angle) {
+    if (pair_has_nan<DIM>(in1, in2)) return __builtin_nanf("");   // torch.clamp propagates NaN (sph_iou_api.py:86)
     float b1[5], b2[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) { b1[k] = in1[k]; b2[k] = in2[k]; }

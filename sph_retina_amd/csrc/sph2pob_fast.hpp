@@ -74,6 +74,45 @@ SPH_DEV void sincos_r(float x, float& s, float& c) {
     c = ((q + 1) & 2) ? -b : b;
 }
 
+// The same reduction and polynomials with cheaper quadrant logic for the two argument ranges of stage 1 (the generic
+// selection above costs 12 compare / select / integer instructions per call, as much as the polynomials themselves):
+// sin / cos of a colatitude x in [0, pi] — what the spherical jitter's clamps guarantee: k in {0, 1, 2}, sin >= 0.
+// Bit-identical to sincos_r on that range.
+SPH_DEV void sincos_colat(float x, float& s, float& c) {
+    float k = rintf(x * 0.63661977236758134f);
+    float r = fmaf(-k, 1.5703125f, x);
+    r = fmaf(-k, 4.837512969970703125e-4f, r);
+    r = fmaf(-k, 7.549789954891882e-8f, r);
+    float z = r * r;
+    float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    float sp = fmaf(r * z, ps, r);
+    float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    float cp = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+    const bool odd = k == 1.0f;
+    const float a = odd ? cp : sp, b = odd ? sp : cp;
+    s = fabsf(a);               // k = 2: r in [-pi/4, 0], sin x = -sin r >= 0
+    c = k >= 1.0f ? -b : b;     // cos(pi/2 + r) = -sin r, cos(pi + r) = -cos r
+}
+// sin(2x) and 1 - cos(2x) for x in [-pi, pi] (half the longitude difference of two clamped longitudes): both are
+// invariant under (sin x, cos x) -> (-sin x, -cos x), so only the parity of the quadrant matters.  Bit-identical to
+// 2 sh ch / 2 sh sh from sincos_r on that range.
+SPH_DEV void sin_vers_double(float x, float& sin2x, float& vers2x) {
+    float k = rintf(x * 0.63661977236758134f);
+    float r = fmaf(-k, 1.5703125f, x);
+    r = fmaf(-k, 4.837512969970703125e-4f, r);
+    r = fmaf(-k, 7.549789954891882e-8f, r);
+    float z = r * r;
+    float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    float sp = fmaf(r * z, ps, r);
+    float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    float cp = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+    const bool odd = fabsf(k) == 1.0f;
+    const float t = sp * cp, t2 = t + t;
+    sin2x = odd ? -t2 : t2;
+    const float a = odd ? cp : sp;
+    vers2x = 2.0f * a * a;
+}
+
 // atan(t), 0 <= t <= 1 (|err| <= 1.3e-7): odd polynomial of degree 17, near-minimax fit.
 SPH_DEV float atan_unit(float t) {
     float u = t * t;
@@ -209,16 +248,17 @@ SPH_DEV CullBox cull_box(const float (&b)[5], int edge) {
     // clamps only shrink extents; both are far inside the 1.5e-3 rad margin.  Extents are clamped to the jitter's
     // upper bound (180 deg) so that an out-of-range alpha/beta cannot under-estimate the radius; phi is clamped
     // into [0, 180] like the jitter does; theta enters only through cos(theta_p - theta_g) (periodic).
-    float w = fminf(b[2], 180.0f) * kDeg2Rad, h = fminf(b[3], 180.0f) * kDeg2Rad;
+    // (NaN-propagating clamps: a NaN coordinate makes the pair's test false, i.e. the pair is never culled)
+    float w = min_nan(b[2], 180.0f) * kDeg2Rad, h = min_nan(b[3], 180.0f) * kDeg2Rad;
     if (edge != EDGE_ARC) { w = edge_length(w, edge); h = edge_length(h, edge); }
     float d = w * w + h * h;
     const float kRev = 1.0f / 360.0f;
-    float ph = fminf(fmaxf(b[1], 0.0f), 180.0f) * kRev;
+    float ph = min_nan(max_nan(b[1], 0.0f), 180.0f) * kRev;
     CullBox cb;
     cb.s = hw_sin_rev(ph);
     cb.c = hw_cos_rev(ph);
-    cb.th_rev = fminf(fmaxf(b[0], 0.0f), 360.0f) * kRev;
-    cb.r = d > 0.0f ? 0.5f * d * fast_rsq(d) : __builtin_inff();
+    cb.th_rev = min_nan(max_nan(b[0], 0.0f), 360.0f) * kRev;
+    cb.r = d > 0.0f ? 0.5f * d * fast_rsq(d) : __builtin_inff();   // d = NaN -> +inf: never culled
     return cb;
 }
 // Per-pair part: true when the circumscribed circles cannot touch (IoU exactly 0).  1 - R^2/2 + R^4/24 - R^6/720
@@ -244,16 +284,17 @@ SPH_DEV bool fast_cull(const float (&g)[5], const float (&p)[5], int edge) {
     // scale first, clamp second: the product is a canonical number, so the compiler does not have to quiet a possible
     // signalling NaN of the loaded value (v_max x, x) in front of every v_min / v_max; same values (monotone rounding)
     const float kPiHi = 180.0f * kDeg2Rad;
-    float wg = fminf(g[2] * kDeg2Rad, kPiHi), hg = fminf(g[3] * kDeg2Rad, kPiHi);
-    float wp = fminf(p[2] * kDeg2Rad, kPiHi), hp = fminf(p[3] * kDeg2Rad, kPiHi);
+    // NaN-propagating clamps: any NaN coordinate ends in R2 or C and makes the final comparison false (not culled)
+    float wg = min_nan(g[2] * kDeg2Rad, kPiHi), hg = min_nan(g[3] * kDeg2Rad, kPiHi);
+    float wp = min_nan(p[2] * kDeg2Rad, kPiHi), hp = min_nan(p[3] * kDeg2Rad, kPiHi);
     if (edge != EDGE_ARC) { wg = edge_length(wg, edge); hg = edge_length(hg, edge); wp = edge_length(wp, edge); hp = edge_length(hp, edge); }
     const float dg = wg * wg + hg * hg, dp = wp * wp + hp * hp, prod = dg * dp;
     const float R2 = 0.25f * (dg + dp) + 0.5f * (prod * fast_rsq(prod)) + 9.01e-3f;
     const float cosR_lb = fmaf(fmaf(fmaf(-1.0f / 720.0f, R2, 1.0f / 24.0f), R2, -0.5f), R2, 1.0f);
     const float kRev = 1.0f / 360.0f;
     // latitudes / longitudes in revolutions, clamped like the jitter clamps them (phi to [0, 180], theta to [0, 360] deg)
-    const float phg = fminf(fmaxf(g[1] * kRev, 0.0f), 0.5f), php = fminf(fmaxf(p[1] * kRev, 0.0f), 0.5f);
-    const float thg = fminf(fmaxf(g[0] * kRev, 0.0f), 1.0f), thp = fminf(fmaxf(p[0] * kRev, 0.0f), 1.0f);
+    const float phg = min_nan(max_nan(g[1] * kRev, 0.0f), 0.5f), php = min_nan(max_nan(p[1] * kRev, 0.0f), 0.5f);
+    const float thg = min_nan(max_nan(g[0] * kRev, 0.0f), 1.0f), thp = min_nan(max_nan(p[0] * kRev, 0.0f), 1.0f);
     const float u = hw_cos_rev(phg - php), v = hw_cos_rev(phg + php);
     const float cD = hw_cos_rev(thp - thg);
     const float C = 0.5f * ((u + v) + (u - v) * cD);
@@ -264,7 +305,9 @@ SPH_DEV bool fast_cull(const float (&g)[5], const float (&p)[5], int edge) {
 struct FastTrig { float sg, cg, sp, cp, sD, cD; };
 
 // Stage 1: accurate trig on the jittered boxes, bearing numerators, and the exact early-out on accurate values.
-template <int VARIANT, int DIM>
+// CLAMPED: the boxes went through jitter_spherical (phi in [0, 180], theta in [0, 360] degrees), which lets the three
+// sincos calls use the cheap quadrant logic; the results are bit-identical either way on that range.
+template <int VARIANT, int DIM, bool CLAMPED = true>
 SPH_DEV int fast_phase1(const float (&b1)[5], const float (&b2)[5], int edge, FastRec& r, FastTrig* trig = nullptr) {
 #pragma clang fp contract(fast)
     // degrees -> radians with the reference's rounding (torch.deg2rad: x * fl32(pi/180))
@@ -273,12 +316,19 @@ SPH_DEV int fast_phase1(const float (&b1)[5], const float (&b2)[5], int edge, Fa
     r.wp = edge_length(b2[2] * kDeg2Rad, edge); r.hp = edge_length(b2[3] * kDeg2Rad, edge);
     r.ga = DIM == 5 ? b1[4] * kDeg2Rad : 0.0f;
     r.gb = DIM == 5 ? b2[4] * kDeg2Rad : 0.0f;
-    float sg, cg, sp, cp, sh, ch;
-    sincos_r(phg, sg, cg);
-    sincos_r(php, sp, cp);
-    sincos_r(0.5f * (thp - thg), sh, ch);
-    float sD = 2.0f * sh * ch;   // sin(theta_p - theta_g)
-    float h2 = 2.0f * sh * sh;   // 1 - cos(theta_p - theta_g)
+    float sg, cg, sp, cp, sD, h2;   // sD = sin(theta_p - theta_g), h2 = 1 - cos(theta_p - theta_g)
+    if (CLAMPED) {
+        sincos_colat(phg, sg, cg);
+        sincos_colat(php, sp, cp);
+        sin_vers_double(0.5f * (thp - thg), sD, h2);
+    } else {
+        float sh, ch;
+        sincos_r(phg, sg, cg);
+        sincos_r(php, sp, cp);
+        sincos_r(0.5f * (thp - thg), sh, ch);
+        sD = 2.0f * sh * ch;
+        h2 = 2.0f * sh * sh;
+    }
     float q = sp * cg - cp * sg; // sin(phi_p - phi_g)
     r.N = q - sp * cg * h2;  r.D = -sp * sD;
     r.Np = q + sg * cp * h2; r.Dp = -sg * sD;
@@ -417,25 +467,19 @@ SPH_DEV float planar_area2(const PlanarPair& q, float c, float s, bool robust) {
     }
     return t2;
 }
-// Phase 2: planar boxes, then boundary-integral intersection and IoU.  ROBUST (SPH2POB_FLAG_ROBUST_PARALLEL): pairs
-// left nearly parallel by a cancellation of the reference's two jitter steps are evaluated with near_parallel_inter;
-// compile-time because the branch costs every pair 4.5 % (6 more VGPRs, tools/ab_near_parallel.sh) even when not taken.
-template <int VARIANT, int DIM, bool ROBUST = false>
+// Phase 2 (general form): planar boxes with every rare branch of the reference (acos floors, both jitters' decisions,
+// angle clamps), then the boundary-integral intersection and the IoU.  Pairs left nearly parallel by a cancellation of
+// the reference's two jitter steps are evaluated with near_parallel_inter.  This is the slow, complete
+// path: the kernels send only the rare lanes through it (lean_stage1 below decides which), so its extra branches cost
+// the common pair nothing.
+template <int VARIANT, int DIM>
 SPH_DEV float fast_phase2(const FastRec& r, int mode) {
 #pragma clang fp contract(fast)
     PlanarPair q;
     fast_planar<VARIANT, DIM>(r, q);
     float c = q.ca * q.cb + q.sa * q.sb, s = q.sa * q.cb - q.ca * q.sb;
-    float t2 = planar_area2(q, c, s, false);
-    if constexpr (ROBUST) {
-        const bool near = fminf(fabsf(s), fabsf(c)) < kNearParallel;
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (__ballot(near) != 0ull)    // wave-uniform: ~2 % of the waves hold such a pair
-#else
-        if (near)
-#endif
-            t2 = planar_area2(q, c, s, true);
-    }
+    const bool near = fminf(fabsf(s), fabsf(c)) < kNearParallel;
+    float t2 = planar_area2(q, c, s, near);
     float inter = 0.5f * fmaxf(t2, 0.0f);
     float a1 = q.wg * q.hg, a2 = q.wp * q.hp;
     float base = mode == MODE_IOU ? (a1 + a2 - inter) : a1;
@@ -445,23 +489,142 @@ SPH_DEV float fast_phase2(const FastRec& r, int mode) {
     return fminf(fmaxf(iou, 0.0f), 1.0f);
 }
 
-// Spherical jitter + stages 1 + 2 for a pair that survived the cull.
-template <int VARIANT, int DIM, bool ROBUST = false>
+// Spherical jitter + stages 1 + 2 for one pair, general form.  A NaN coordinate gives NaN, as the reference's
+// torch.clamp chain does (sph_iou_api.py:86, :244-260) — v_med3 / fmin / fmax on the way would otherwise drop it.
+template <int VARIANT, int DIM>
 SPH_DEV float fast_finish(const float (&in1)[5], const float (&in2)[5], int mode, int edge) {
+    if (pair_has_nan<DIM>(in1, in2)) return __builtin_nanf("");
     float j1[5], j2[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) { j1[k] = in1[k]; j2[k] = in2[k]; }
     jitter_spherical<DIM>(j1, j2);
     FastRec r;
     if (fast_phase1<VARIANT, DIM>(j1, j2, edge, r) == FAST_ZERO) return 0.0f;
-    return fast_phase2<VARIANT, DIM, ROBUST>(r, mode);
+    return fast_phase2<VARIANT, DIM>(r, mode);
 }
 
-// VARIANT: 0 standard, 1 efficient.  Returns clamp(IoU, 0, 1) of one pair.
-template <int VARIANT, int DIM, bool ROBUST = false>
+// ---------------------------------------------------------------------------------------------------------------------
+// Lean pipeline (the common pair).  The compacting kernels run three stages with an LDS stack between them:
+//   stage 0  fast_cull / cull_pair       all pairs       bounding circles, hardware trig                  ~60 % leave
+//   stage 1  lean_stage1                 cull survivors  jitter clamps, accurate trig, bearings, A, exact
+//                                                        separating-axis test; classifies the lane          ~35 % leave
+//   stage 2  lean_stage2                 SAT survivors   the 8-edge boundary integral and the IoU — straight-line code
+// A lane is RARE when any branch of the general form could fire for it: a NaN, the spherical jitter's `similar`, an
+// acos floor (|sin a| < 4.88e-4, A < ~1e-3), the rotated jitter's `similar` / `close` decisions (which need real
+// angles), its size clamps, |gamma| > 3.1, or planar boxes within kNearParallel of parallel / perpendicular.  Rare lanes
+// (~1e-3 of the benchmark distribution) are finished in place by fast_finish; for every other lane the general form
+// would take none of its branches and compute exactly what stages 1 + 2 compute.
+//
+// The SAT is exact in the sense of stage 0: it only rejects pairs whose planar rectangles are disjoint in the
+// reference's own (fp32-noisy, jittered) evaluation, for which the reference returns exactly 0.  Margins: the two
+// rectangles' relative position is uncertain by < 1.75e-3 (both jitters' shifts and growth, the reference's rounding
+// of A — the bound stage 0 uses), every angle by < 5e-3 rad (rotated jitter <= 3.1e-3, the reference's acos(clamp(.))
+// noise and floors <= 1e-3); a rotation by delta moves a projected extent by <= delta * (A + w + h) of the boxes
+// involved.  m = 2e-3 + 5e-3 * (A + w_g + h_g + w_p + h_p) covers both on all four axes.
+struct LeanRec { float A, ca, sa, cb, sb, wg, hg, wp, hp; };
+enum : int { LEAN_ZERO = 0, LEAN_SURVIVOR = 1, LEAN_RARE = 2 };
+
+template <int VARIANT, int DIM>
+SPH_DEV int lean_stage1(const float (&in1)[5], const float (&in2)[5], int edge, LeanRec& o) {
+#pragma clang fp contract(fast)
+    const float eps = (float)kEpsS, eps2 = (float)(2 * kEpsS);
+    bool rare = pair_has_nan<DIM>(in1, in2);
+#pragma unroll
+    for (int k = 0; k < DIM; k++) rare |= fabsf(in1[k] - in2[k]) < eps;   // jitter_spherical's `similar`
+    // jitter_spherical without the shift (not similar): the clamps (sph_iou_api.py:251-258)
+    const float th1 = clampf(in1[0], eps2, (float)(360.0 - kEpsS)), th2 = clampf(in2[0], eps, (float)(360.0 - 2 * kEpsS));
+    const float ph1 = clampf(in1[1], eps2, (float)(180.0 - kEpsS)), ph2 = clampf(in2[1], eps, (float)(180.0 - 2 * kEpsS));
+    const float al1 = clampf(in1[2], eps2, (float)(180.0 - kEpsS)), al2 = clampf(in2[2], eps, (float)(180.0 - 2 * kEpsS));
+    const float be1 = clampf(in1[3], eps2, (float)(180.0 - kEpsS)), be2 = clampf(in2[3], eps, (float)(180.0 - 2 * kEpsS));
+    float ga1 = 0.0f, ga2 = 0.0f;
+    if (DIM == 5) {
+        ga1 = in1[4];
+        ga2 = clampf(in2[4], (float)(-360.0 + 2 * kEpsS), (float)(360.0 - 2 * kEpsS));
+    }
+    // degrees -> radians with the reference's rounding, as fast_phase1
+    const float thg = th1 * kDeg2Rad, phg = ph1 * kDeg2Rad, thp = th2 * kDeg2Rad, php = ph2 * kDeg2Rad;
+    const float wg = edge_length(al1 * kDeg2Rad, edge), hg = edge_length(be1 * kDeg2Rad, edge);
+    const float wp = edge_length(al2 * kDeg2Rad, edge), hp = edge_length(be2 * kDeg2Rad, edge);
+    float sg, cg, sp, cp, sD, h2;
+    sincos_colat(phg, sg, cg);
+    sincos_colat(php, sp, cp);
+    sin_vers_double(0.5f * (thp - thg), sD, h2);
+    const float q = sp * cg - cp * sg;
+    const float N = q - sp * cg * h2, D = -sp * sD;
+    const float Np = q + sg * cp * h2, Dp = -sg * sD;
+    const float C = (cg * cp + sg * sp) - sg * sp * h2;
+    const float S2 = N * N + D * D;
+    const float iS = fast_rsq(S2);
+    // A >= sin A > 1.05e-3 keeps clear of the acos floors (9.77e-4 standard / 4.88e-4 efficient), of the rotated
+    // jitter's `A < eps` and of the undefined bearing of coincident centres; antipodal centres (S2 ~ 0 too) go the same way
+    rare |= !(S2 > 1.1e-6f);
+    const float A = atan2_r(S2 * iS, C);
+    float ca = D * iS, sa = N * iS, cb = Dp * iS, sb = Np * iS;
+    if (DIM == 5) {
+        const float ga = ga1 * kDeg2Rad, gb = ga2 * kDeg2Rad;
+        rare |= (fabsf(ga) > 3.1f) | (fabsf(gb) > 3.1f);
+        if (VARIANT == VARIANT_EFFICIENT) rare |= (fabsf(sa) < kMinAng) | (fabsf(sb) < kMinAng);   // floor, then a -= gamma
+        float sga, cga, sgb, cgb;
+        sincos_r(ga, sga, cga);
+        sincos_r(gb, sgb, cgb);
+        rot(ca, sa, cga, -sga);
+        rot(cb, sb, cgb, -sgb);
+        if (VARIANT == VARIANT_STANDARD) rare |= (fabsf(sa) < kMinAng) | (fabsf(sb) < kMinAng);    // d rotated first
+    } else {
+        rare |= (fabsf(sa) < kMinAng) | (fabsf(sb) < kMinAng);
+    }
+    const float c = ca * cb + sa * sb, s = sa * cb - ca * sb;   // cos / sin of (a_g - a_p)
+    const float as = fabsf(s), ac = fabsf(c);
+    // rotated jitter: `similar` on sizes, the angle decisions' candidate range, the size clamps; near-parallel boxes
+    rare |= (fabsf(wg - wp) < eps) | (fabsf(hg - hp) < eps);
+    rare |= (c > 0.5f) & (as < 2.0e-3f);
+    rare |= fminf(as, ac) < kNearParallel;
+    rare |= (fminf(wg, hg) < (float)(2 * kEpsA / 10)) | (fminf(wp, hp) < (float)(kEpsA / 10));
+    if (rare) return LEAN_RARE;
+    // separating-axis test on the four edge normals: p's centre in g's frame is (A ca, -A sa), g's centre in p's frame
+    // (-A cb, A sb); half extents of the other box projected with (|c|, |s|)
+    const float m2 = 2.0f * (2.0e-3f + 5.0e-3f * (A + ((wg + hg) + (wp + hp))));   // margin, doubled like the extents
+    const float ex_g = wg + (ac * wp + as * hp) + m2, ey_g = hg + (as * wp + ac * hp) + m2;
+    const float ex_p = wp + (ac * wg + as * hg) + m2, ey_p = hp + (as * wg + ac * hg) + m2;
+    const float A2 = A + A;
+    const bool apart = (A2 * fabsf(ca) > ex_g) | (A2 * fabsf(sa) > ey_g) | (A2 * fabsf(cb) > ex_p) | (A2 * fabsf(sb) > ey_p);
+    if (apart) return LEAN_ZERO;
+    o.A = A; o.ca = ca; o.sa = sa; o.cb = cb; o.sb = sb; o.wg = wg; o.hg = hg; o.wp = wp; o.hp = hp;
+    return LEAN_SURVIVOR;
+}
+
+// Stage 2 of the lean pipeline: boundary integral + IoU of a non-rare pair (P at the origin, T at (A, 0); no jitter
+// branch fired, no clamp is active, |sin|, |cos| of the relative angle >= kNearParallel so the reciprocals need no
+// clamping).  Same arithmetic as fast_phase2 executes for such a lane.
+SPH_DEV float lean_stage2(const LeanRec& r, int mode) {
+#pragma clang fp contract(fast)
+    const float c = r.ca * r.cb + r.sa * r.sb, s = r.sa * r.cb - r.ca * r.sb;
+    const float ic = fast_rcp(c), is = fast_rcp(s);
+    const float aic = fabsf(ic), ais = fabsf(is);
+    const float hwa = 0.5f * r.wg, hha = 0.5f * r.hg, hwb = 0.5f * r.wp, hhb = 0.5f * r.hp;
+    const float pax = -(r.A * r.cb), pay = r.A * r.sb;
+    const float pbx = r.A * r.ca, pby = -(r.A * r.sa);
+    const float t2 = edges_inside3(pax, pay, c, s, ic, is, aic, ais, hwa, hha, hwb, hhb, r.wg, r.hg, true) +
+                     edges_inside3(pbx, pby, c, -s, ic, -is, aic, ais, hwb, hhb, hwa, hha, r.wp, r.hp, false);
+    const float inter = 0.5f * fmaxf(t2, 0.0f);
+    const float a1 = r.wg * r.hg, a2 = r.wp * r.hp;
+    const float base = mode == MODE_IOU ? (a1 + a2 - inter) : a1;
+    float rb = fast_rcp(base);
+    rb = rb * (2.0f - base * rb);
+    const float iou = inter * rb;
+    return fminf(fmaxf(iou, 0.0f), 1.0f);
+}
+
+// One pair through the lean pipeline without compaction (the one-lane-per-pair kernels, NMS rows, host tests): the
+// same classification and the same arithmetic per class as the compacting kernels, hence bit-identical results.
+template <int VARIANT, int DIM>
 SPH_DEV float pair_iou_fast(const float (&in1)[5], const float (&in2)[5], int mode, int edge) {
     if (fast_cull<DIM>(in1, in2, edge)) return 0.0f;
-    return fast_finish<VARIANT, DIM, ROBUST>(in1, in2, mode, edge);
+    LeanRec r;
+    const int st = lean_stage1<VARIANT, DIM>(in1, in2, edge, r);
+    if (st == LEAN_ZERO) return 0.0f;
+    if (st == LEAN_RARE) return fast_finish<VARIANT, DIM>(in1, in2, mode, edge);
+    return lean_stage2(r, mode);
 }
 
 }  // namespace sph2pob

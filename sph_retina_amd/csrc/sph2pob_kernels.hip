@@ -74,47 +74,104 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_kernel(const float* __rest
     out[i] = pair_iou_sel<VARIANT, DIM, FAST>(x, y, mode, edge, angle);
 }
 
-// ---- dominant kernel: aligned IoU, closed-form core, with wave-level compaction of early-out survivors ----
+// ---- dominant kernel: aligned IoU, closed-form core, three stages with wave-level compaction between them ----
 // ~60 % of the benchmark distribution's pairs are culled exactly by the bounding-circle test of stage 0 (hardware
-// sin/cos, conservative margins); only survivors pay for accurate trig and the clip.  A naive
-// `if (!culled) phase2` leaves every wave running phase 2 with ~40 % of its lanes.  Here each wave walks 64-pair
-// slices, pushes the survivors' phase-1 records into its own LDS stack (ballot + prefix rank => conflict-free
-// consecutive slots, no atomics, no barriers: LDS operations of one wave are in order), and runs phase 2 only
-// when 64 records are available, i.e. on fully populated waves.  Leftovers of the 4 waves of a workgroup are
-// merged once at the end.  Stores: culled pairs write 0 from phase 1, survivors write from phase 2 by index.
-constexpr int kQCap = 128;                    // per-wave stack capacity (<= 63 carried + 64 pushed)
-constexpr int kQFields = 10;                  // raw (theta, phi, alpha, beta[, gamma]) of both boxes
-
-struct WaveQueue {
-    float f[kQFields][kQCap];
-    int idx[kQCap];
+// sin/cos, conservative margins); of the survivors another ~35 % are rejected exactly by the separating-axis test at
+// the end of stage 1 (accurate trig, bearings, A): only 26 % of the pairs overlap and only those need the clip.  A
+// naive `if (!culled) ...` leaves every wave running each later stage with 40 % / 26 % of its lanes.  Here each wave
+// walks 64-pair slices and keeps two LDS stacks: S1 takes the cull survivors' raw boxes, S2 the SAT survivors' planar
+// records (ballot + prefix rank => conflict-free consecutive slots, no atomics, no barriers: LDS operations of one
+// wave are in order).  A stage runs only when 64 records are available, i.e. on fully populated waves.  Rare lanes
+// (jitter decisions, acos floors, near-parallel boxes, NaN: lean_stage1) are finished in place by the general form.
+// The two stacks share one array and grow towards each other: S1 from slot 0 up, S2 from the last slot down; at any
+// time S1 <= 127 with S2 <= 63, or S1 <= 63 with S2 <= 127, so 192 slots suffice (7.7 KB per wave for BFoV: 5
+// workgroups per CU).  Leftovers of the 4 waves of a workgroup are merged once per stack at the end.
+// Stores: culled / separated pairs write 0 from their stage, survivors write from stage 2 (or the general form) by index.
+constexpr int kPipeSlots = 192;
+template <int DIM>
+struct PipeQueue {
+    static constexpr int kFields = DIM == 4 ? 9 : 10;   // S1: 2 * DIM raw coordinates; S2: the 9 floats of a LeanRec
+    float f[kFields][kPipeSlots];
+    int idx[kPipeSlots];
 };
+constexpr int pipe_lds_bytes(int dim) { return (kBlock / 64) * ((dim == 4 ? 9 : 10) + 1) * kPipeSlots * 4 + 64; }
 
 template <int DIM>
-__device__ __forceinline__ void queue_store(WaveQueue& q, int slot, const float (&j1)[5], const float (&j2)[5], int i) {
+__device__ __forceinline__ void s1_store(PipeQueue<DIM>& q, int slot, const float (&j1)[5], const float (&j2)[5], int i) {
 #pragma unroll
-    for (int k = 0; k < DIM; k++) { q.f[k][slot] = j1[k]; q.f[5 + k][slot] = j2[k]; }
+    for (int k = 0; k < DIM; k++) { q.f[k][slot] = j1[k]; q.f[DIM + k][slot] = j2[k]; }
     q.idx[slot] = i;
 }
 template <int DIM>
-__device__ __forceinline__ int queue_load(const WaveQueue& q, int slot, float (&j1)[5], float (&j2)[5]) {
+__device__ __forceinline__ int s1_load(const PipeQueue<DIM>& q, int slot, float (&j1)[5], float (&j2)[5]) {
 #pragma unroll
-    for (int k = 0; k < 5; k++) { j1[k] = k < DIM ? q.f[k][slot] : 0.0f; j2[k] = k < DIM ? q.f[5 + k][slot] : 0.0f; }
+    for (int k = 0; k < 5; k++) { j1[k] = k < DIM ? q.f[k][slot] : 0.0f; j2[k] = k < DIM ? q.f[DIM + k][slot] : 0.0f; }
     return q.idx[slot];
 }
+template <int DIM>
+__device__ __forceinline__ void s2_store(PipeQueue<DIM>& q, int j, const LeanRec& r, int i) {
+    const int slot = kPipeSlots - 1 - j;
+    q.f[0][slot] = r.A;  q.f[1][slot] = r.ca; q.f[2][slot] = r.sa; q.f[3][slot] = r.cb; q.f[4][slot] = r.sb;
+    q.f[5][slot] = r.wg; q.f[6][slot] = r.hg; q.f[7][slot] = r.wp; q.f[8][slot] = r.hp;
+    q.idx[slot] = i;
+}
+template <int DIM>
+__device__ __forceinline__ int s2_load(const PipeQueue<DIM>& q, int j, LeanRec& r) {
+    const int slot = kPipeSlots - 1 - j;
+    r.A = q.f[0][slot];  r.ca = q.f[1][slot]; r.sa = q.f[2][slot]; r.cb = q.f[3][slot]; r.sb = q.f[4][slot];
+    r.wg = q.f[5][slot]; r.hg = q.f[6][slot]; r.wp = q.f[7][slot]; r.hp = q.f[8][slot];
+    return q.idx[slot];
+}
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// position of the k-th leftover record in the concatenation of the four waves' stacks: (wave, index in its stack)
+__device__ __forceinline__ void locate_leftover(int k, int c0, int c1, int c2, int& w, int& r) {
+    w = 0;
+    if (k >= c0) { k -= c0; w = 1; if (k >= c1) { k -= c1; w = 2; if (k >= c2) { k -= c2; w = 3; } } }
+    r = k;
+}
 
-template <int VARIANT, int DIM, bool PREFETCH, bool ROBUST = false>
-__global__ __launch_bounds__(kBlock) void iou_aligned_compact_kernel(const float* __restrict__ b1,
-                                                                    const float* __restrict__ b2,
-                                                                    float* __restrict__ out, int n, int mode,
-                                                                    int edge) {
-    __shared__ WaveQueue queues[kBlock / 64];
-    __shared__ int leftover[kBlock / 64];
+// ARC: rbb_edge == 'arc' folded at compile time (the chord / tangent forms pull ocml's sinf / tanf argument reduction
+// into the cull and stage 1: 8 copies of ~100 instructions the common launch never executes)
+template <int VARIANT, int DIM, bool PREFETCH, bool ARC>
+__global__ __launch_bounds__(kBlock) void iou_aligned_pipe_kernel(const float* __restrict__ b1,
+                                                                 const float* __restrict__ b2,
+                                                                 float* __restrict__ out, int n, int mode,
+                                                                 int edge_arg) {
+    __shared__ PipeQueue<DIM> queues[kBlock / 64];
+    __shared__ int left1[kBlock / 64], left2[kBlock / 64];
+    const int edge = ARC ? (int)EDGE_ARC : edge_arg;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    WaveQueue& q = queues[wave];
+    PipeQueue<DIM>& q = queues[wave];
     const int nslices = (n + 63) >> 6;
     const int wave_global = blockIdx.x * (kBlock / 64) + wave, nwaves = gridDim.x * (kBlock / 64);
-    int count = 0;  // wave-uniform stack height
+    int c1 = 0, c2 = 0;  // wave-uniform stack heights
+    // stage 1 on one record per lane (taken from `src`'s S1), survivors pushed on this wave's own S2
+    auto stage1 = [&](const PipeQueue<DIM>& src, int slot, bool active) {
+        bool surv = false;
+        LeanRec rec;
+        int j = 0;
+        if (active) {
+            float u1[5], u2[5];
+            j = s1_load<DIM>(src, slot, u1, u2);
+            const int st = lean_stage1<VARIANT, DIM>(u1, u2, edge, rec);
+            if (st == LEAN_ZERO) out[j] = 0.0f;
+            else if (st == LEAN_RARE) out[j] = fast_finish<VARIANT, DIM>(u1, u2, mode, edge);
+            else surv = true;
+        }
+        const unsigned long long m = __ballot(surv);
+        if (surv) s2_store<DIM>(q, c2 + __popcll(m & ((1ull << lane) - 1ull)), rec, j);
+        c2 += __popcll(m);
+    };
+    auto stage2 = [&](const PipeQueue<DIM>& src, int j2, bool active) {
+        if (active) {
+            LeanRec rec;
+            const int j = s2_load<DIM>(src, j2, rec);
+            out[j] = lean_stage2(rec, mode);
+        }
+    };
     // software prefetch: the next slice's boxes are in flight while this slice is computed (register double buffer)
     float nx[5], ny[5];
     {
@@ -139,30 +196,48 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_compact_kernel(const float
             else surv = true;
         }
         const unsigned long long m = __ballot(surv);
-        if (surv) queue_store<DIM>(q, count + __popcll(m & ((1ull << lane) - 1ull)), x, y, i);
-        count += __popcll(m);
-        if (count >= 64) {  // wave-uniform
-            count -= 64;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            float u1[5], u2[5];
-            int j = queue_load<DIM>(q, count + lane, u1, u2);
-            out[j] = fast_finish<VARIANT, DIM, ROBUST>(u1, u2, mode, edge);
+        if (surv) s1_store<DIM>(q, c1 + __popcll(m & ((1ull << lane) - 1ull)), x, y, i);
+        c1 += __popcll(m);
+        if (c1 >= 64) {  // wave-uniform
+            c1 -= 64;
+            wave_lds_fence();
+            stage1(q, c1 + lane, true);
+            if (c2 >= 64) {
+                c2 -= 64;
+                wave_lds_fence();
+                stage2(q, c2 + lane, true);
+            }
         }
     }
-    // merge the < 64 leftovers of the four waves and finish them on as few, as full waves as possible
-    if (lane == 0) leftover[wave] = count;
+    // merge the < 64 S1 leftovers of the four waves and run stage 1 on as few, as full waves as possible (a wave reads
+    // other waves' S1 slots [0, 63) and pushes on its own S2, slots >= 65: no overlap)
+    if (lane == 0) left1[wave] = c1;
     __syncthreads();
-    const int c0 = leftover[0], c1 = leftover[1], c2 = leftover[2], c3 = leftover[3];
-    const int total = c0 + c1 + c2 + c3;
-    for (int base = wave * 64; base < total; base += kBlock) {
-        int k = base + lane;
-        if (k < total) {
-            int w = 0;
-            if (k >= c0) { k -= c0; w = 1; if (k >= c1) { k -= c1; w = 2; if (k >= c2) { k -= c2; w = 3; } } }
-            float u1[5], u2[5];
-            int j = queue_load<DIM>(queues[w], k, u1, u2);
-            out[j] = fast_finish<VARIANT, DIM, ROBUST>(u1, u2, mode, edge);
+    {
+        const int a0 = left1[0], a1 = left1[1], a2 = left1[2], a3 = left1[3];
+        const int total = a0 + a1 + a2 + a3;       // <= 252: at most one chunk per wave
+        const int k = wave * 64 + lane;
+        if (wave * 64 < total) {
+            int w, r;
+            locate_leftover(k, a0, a1, a2, w, r);
+            stage1(queues[w], r, k < total);
+            if (c2 >= 64) {
+                c2 -= 64;
+                wave_lds_fence();
+                stage2(q, c2 + lane, true);
+            }
+        }
+    }
+    if (lane == 0) left2[wave] = c2;
+    __syncthreads();
+    {
+        const int a0 = left2[0], a1 = left2[1], a2 = left2[2], a3 = left2[3];
+        const int total = a0 + a1 + a2 + a3;
+        const int k = wave * 64 + lane;
+        if (wave * 64 < total) {
+            int w, r;
+            locate_leftover(k, a0, a1, a2, w, r);
+            stage2(queues[w], r, k < total);
         }
     }
 }
@@ -170,17 +245,26 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_compact_kernel(const float
 // ---- pairwise IoU for the assigner call pattern (few rows x many columns), closed-form core ----
 // One thread owns one column box (anchor); a workgroup covers 256 columns x up to 64 rows (GT).  Per-box cull
 // quantities are hoisted: rows live in LDS (broadcast reads), the column's in registers, so a culled pair costs
-// ~15 VALU instructions + one coalesced store of 0.  Survivors are (row, column) index pairs pushed on the wave's
-// LDS stack and finished 64 at a time on fully populated waves (same scheme as iou_aligned_compact_kernel).
+// ~15 VALU instructions + one coalesced store of 0.  Cull survivors are (row, column) index pairs on the wave's S1
+// stack; stage 1 runs on 64 of them at a time (row box from LDS, column box re-read through L1/L2) and pushes the
+// separating-axis survivors' planar records on S2; stage 2 (the clip) again runs on fully populated waves — the same
+// three-stage scheme as iou_aligned_pipe_kernel, with the wave's own leftovers finished at the end (no merging:
+// a wave handles rows x 64 pairs, the leftover share is small).
 constexpr int kPwRows = 64;
-template <int VARIANT, int DIM, bool ROBUST = false>
+constexpr int kPwSlots = 128;   // S1 and S2 separately (S1 is 8 bytes per slot)
+struct PairQueue {
+    int2 s1[kPwSlots];
+    float f[9][kPwSlots];
+    int2 s2[kPwSlots];
+};
+template <int VARIANT, int DIM>
 __global__ __launch_bounds__(kBlock) void iou_pairwise_compact_kernel(const float* __restrict__ b1, int m,
                                                                      const float* __restrict__ b2, int n,
                                                                      float* __restrict__ out, int mode, int edge,
                                                                      int rows_per_wg) {
     __shared__ float row_raw[kPwRows][5];
     __shared__ float4 row_cull[kPwRows];
-    __shared__ int2 stack[kBlock / 64][kQCap];
+    __shared__ PairQueue queues[kBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = blockIdx.y * rows_per_wg, rows = (m - r0 < rows_per_wg) ? m - r0 : rows_per_wg;
     if ((int)threadIdx.x < rows) {
@@ -197,14 +281,44 @@ __global__ __launch_bounds__(kBlock) void iou_pairwise_compact_kernel(const floa
     float a[5] = {0.0f, 0.0f, 1.0f, 1.0f, 0.0f};
     if (valid) load_box<DIM>(b2, j, a);
     const CullBox ca = cull_box(a, edge);
-    int2* st = stack[wave];
-    int count = 0;
-    auto finish_one = [&](int2 e) {
-        float g[5], p[5];
+    PairQueue& q = queues[wave];
+    int c1 = 0, c2 = 0;
+    auto stage2 = [&](int slot) {
+        LeanRec rec;
+        rec.A = q.f[0][slot];  rec.ca = q.f[1][slot]; rec.sa = q.f[2][slot]; rec.cb = q.f[3][slot]; rec.sb = q.f[4][slot];
+        rec.wg = q.f[5][slot]; rec.hg = q.f[6][slot]; rec.wp = q.f[7][slot]; rec.hp = q.f[8][slot];
+        const int2 e = q.s2[slot];
+        out[(int64_t)(r0 + e.x) * n + e.y] = lean_stage2(rec, mode);
+    };
+    auto stage1 = [&](int slot, bool active) {
+        bool surv = false;
+        LeanRec rec;
+        int2 e = make_int2(0, 0);
+        if (active) {
+            e = q.s1[slot];
+            float g[5], p[5];
 #pragma unroll
-        for (int k = 0; k < 5; k++) g[k] = row_raw[e.x][k];
-        load_box<DIM>(b2, e.y, p);
-        out[(int64_t)(r0 + e.x) * n + e.y] = fast_finish<VARIANT, DIM, ROBUST>(g, p, mode, edge);
+            for (int k = 0; k < 5; k++) g[k] = row_raw[e.x][k];
+            load_box<DIM>(b2, e.y, p);
+            const int st = lean_stage1<VARIANT, DIM>(g, p, edge, rec);
+            float* dst = out + (int64_t)(r0 + e.x) * n + e.y;
+            if (st == LEAN_ZERO) *dst = 0.0f;
+            else if (st == LEAN_RARE) *dst = fast_finish<VARIANT, DIM>(g, p, mode, edge);
+            else surv = true;
+        }
+        const unsigned long long mk = __ballot(surv);
+        if (surv) {
+            const int s = c2 + __popcll(mk & ((1ull << lane) - 1ull));
+            q.f[0][s] = rec.A;  q.f[1][s] = rec.ca; q.f[2][s] = rec.sa; q.f[3][s] = rec.cb; q.f[4][s] = rec.sb;
+            q.f[5][s] = rec.wg; q.f[6][s] = rec.hg; q.f[7][s] = rec.wp; q.f[8][s] = rec.hp;
+            q.s2[s] = e;
+        }
+        c2 += __popcll(mk);
+        if (c2 >= 64) {
+            c2 -= 64;
+            wave_lds_fence();
+            stage2(c2 + lane);
+        }
     };
     for (int i = 0; i < rows; i++) {
         const float4 rc = row_cull[i];
@@ -214,18 +328,18 @@ __global__ __launch_bounds__(kBlock) void iou_pairwise_compact_kernel(const floa
             else surv = true;
         }
         const unsigned long long mk = __ballot(surv);
-        if (surv) st[count + __popcll(mk & ((1ull << lane) - 1ull))] = make_int2(i, j);
-        count += __popcll(mk);
-        if (count >= 64) {
-            count -= 64;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            finish_one(st[count + lane]);
+        if (surv) q.s1[c1 + __popcll(mk & ((1ull << lane) - 1ull))] = make_int2(i, j);
+        c1 += __popcll(mk);
+        if (c1 >= 64) {
+            c1 -= 64;
+            wave_lds_fence();
+            stage1(c1 + lane, true);
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (lane < count) finish_one(st[lane]);
+    wave_lds_fence();
+    if (c1 > 0) stage1(lane, lane < c1);
+    wave_lds_fence();
+    if (lane < c2) stage2(lane);
 }
 
 // out[i*n + j]: consecutive lanes walk j (coalesced stores, b2 loads coalesced, b1 row is a broadcast).
@@ -661,8 +775,7 @@ int launch_status() {
 template <typename F>
 int dispatch(int variant_flags, int box_dim, F&& f) {
     const int variant = variant_flags & 0xff;
-    f.fast = !(variant_flags & SPH2POB_FLAG_REFERENCE_ORDER);
-    f.robust = (variant_flags & SPH2POB_FLAG_ROBUST_PARALLEL) != 0;
+    f.fast = !(variant_flags & SPH2POB_FLAG_REFERENCE_ORDER);   // SPH2POB_FLAG_ROBUST_PARALLEL: accepted, always on now
     if (variant == SPH2POB_VARIANT_STANDARD) return box_dim == 4 ? f.template run<0, 4>() : f.template run<0, 5>();
     if (variant == SPH2POB_VARIANT_EFFICIENT) return box_dim == 4 ? f.template run<1, 4>() : f.template run<1, 5>();
     if (variant == SPH2POB_VARIANT_SPH_IOU) return f.template run<3, 4>();
@@ -673,30 +786,28 @@ int dispatch(int variant_flags, int box_dim, F&& f) {
 }
 
 struct AlignedLaunch {
-    const float *b1, *b2; float* out; int64_t n; int mode, edge, angle; hipStream_t s; bool fast = true, robust = false;
+    const float *b1, *b2; float* out; int64_t n; int mode, edge, angle; hipStream_t s; bool fast = true;
     template <int V, int D> int run() {
         dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
         if (fast && V < 2 && angle == SPH2POB_ANGLE_EQUATOR && n < ((int64_t)1 << 31) - 64 && !g_no_compact) {
-            // persistent-style grid.  Measured on MI355X (tools/sweep_slices.sh, profiles/r01h_sweep_wgs_per_cu.log):
-            // (i) every CU must hold the same number of workgroups — 1 303 workgroups (5.09 per CU) take 11.4 us
-            // for 1 M pairs, 1 536 (6 per CU) take 10.2 us; (ii) 6 per CU (24 waves per CU, LDS allows 7) is the
-            // best or within noise of the best from 125 k to 8 M pairs; (iii) small launches want one slice per wave
-            // rather than full survivor stacks.  Hence: whole multiples of the CU count, at most 6 per CU, at least
-            // one 64-pair slice per wave.
+            // persistent-style grid.  Measured on MI355X (tools/sweep_slices.sh): every CU must hold the same number of
+            // workgroups (1 303 workgroups = 5.09 per CU take 12 % longer than 1 536 = 6 per CU); as many resident
+            // workgroups as the LDS allows (the two stacks: 5 per CU for BFoV, 4 for RBFoV); small launches want one
+            // slice per wave rather than full survivor stacks.  Hence: whole multiples of the CU count, at most the
+            // resident number per CU, at least one 64-pair slice per wave.
             const int64_t kCUs = cu_count();
+            const int64_t resident = (160 * 1024) / pipe_lds_bytes(D);
             int64_t slices = (n + 63) / 64;
             int64_t wgs = (slices + 3) / 4;
             if (g_slices_per_wave > 0) wgs = (slices + 4 * g_slices_per_wave - 1) / (4 * g_slices_per_wave);
-            else if (wgs > kCUs) { wgs = (wgs + kCUs - 1) / kCUs * kCUs; if (wgs > kCUs * 6) wgs = kCUs * 6; }
-            if (wgs > kCUs * 7) wgs = kCUs * 7;
+            else if (wgs > kCUs) { wgs = (wgs + kCUs - 1) / kCUs * kCUs; if (wgs > kCUs * resident) wgs = kCUs * resident; }
             if (g_wgs_per_cu > 0) wgs = kCUs * g_wgs_per_cu;
             if (wgs < 1) wgs = 1;
-            if (g_prefetch && robust)
-                hipLaunchKernelGGL((iou_aligned_compact_kernel<V >= 2 ? 0 : V, D, true, true>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge);
-            else if (g_prefetch)
-                hipLaunchKernelGGL((iou_aligned_compact_kernel<V >= 2 ? 0 : V, D, true>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge);
-            else
-                hipLaunchKernelGGL((iou_aligned_compact_kernel<V >= 2 ? 0 : V, D, false>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge);
+            constexpr int VV = V >= 2 ? 0 : V;
+#define SPH_PIPE(PF, ARC) hipLaunchKernelGGL((iou_aligned_pipe_kernel<VV, D, PF, ARC>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge)
+            if (edge == SPH2POB_EDGE_ARC) { if (g_prefetch) SPH_PIPE(true, true); else SPH_PIPE(false, true); }
+            else { if (g_prefetch) SPH_PIPE(true, false); else SPH_PIPE(false, false); }
+#undef SPH_PIPE
         } else if (fast && V < 2 && angle == SPH2POB_ANGLE_EQUATOR)
             hipLaunchKernelGGL((iou_aligned_kernel<V >= 2 ? 0 : V, D, true>), grid, dim3(kBlock), 0, s, b1, b2, out, n, mode, edge, angle);
         else if (V >= 5 && fast)  // unbiased / naive: `fast` selects the default (double) arithmetic of the unbiased IoU
@@ -707,7 +818,7 @@ struct AlignedLaunch {
     }
 };
 struct PairwiseLaunch {
-    const float* b1; int64_t m; const float* b2; int64_t n; float* out; int mode, edge, angle; hipStream_t s; bool fast = true, robust = false;
+    const float* b1; int64_t m; const float* b2; int64_t n; float* out; int mode, edge, angle; hipStream_t s; bool fast = true;
     template <int V, int D> int run() {
         if (fast && V < 2 && angle == SPH2POB_ANGLE_EQUATOR && n < ((int64_t)1 << 31) - kBlock && m <= (int64_t)65535 * 4 &&
             !g_no_compact) {
@@ -719,12 +830,8 @@ struct PairwiseLaunch {
             if (rpw > kPwRows) rpw = kPwRows;
             if (rpw > m) rpw = m;
             dim3 grid((unsigned)col_tiles, (unsigned)((m + rpw - 1) / rpw));
-            if (robust)
-                hipLaunchKernelGGL((iou_pairwise_compact_kernel<V >= 2 ? 0 : V, D, true>), grid, dim3(kBlock), 0, s, b1, (int)m, b2,
-                                   (int)n, out, mode, edge, (int)rpw);
-            else
-                hipLaunchKernelGGL((iou_pairwise_compact_kernel<V >= 2 ? 0 : V, D>), grid, dim3(kBlock), 0, s, b1, (int)m, b2, (int)n,
-                                   out, mode, edge, (int)rpw);
+            hipLaunchKernelGGL((iou_pairwise_compact_kernel<V >= 2 ? 0 : V, D>), grid, dim3(kBlock), 0, s, b1, (int)m, b2, (int)n,
+                               out, mode, edge, (int)rpw);
             return launch_status();
         }
         // grid.y is limited to 65535 rows per launch: walk the rows in slabs
@@ -748,7 +855,7 @@ struct PairwiseLaunch {
     }
 };
 struct TransformLaunch {
-    const float *b1, *b2; float *o1, *o2; int64_t n; int edge, angle, jitter; hipStream_t s; bool fast = true, robust = false;
+    const float *b1, *b2; float *o1, *o2; int64_t n; int edge, angle, jitter; hipStream_t s; bool fast = true;
     template <int V, int D> int run() {
         dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
         hipLaunchKernelGGL((transform_kernel<V, D>), grid, dim3(kBlock), 0, s, b1, b2, o1, o2, n, edge, angle, jitter);

@@ -142,7 +142,9 @@ SPH_DEV void loss_front_fast(const float (&b1)[5], const float (&b2)[5], LossFro
                              bool rot_jitter = true) {
     FastRec r;
     FastTrig t;
-    fast_phase1<VARIANT, DIM>(b1, b2, edge, r, &t);
+    // rot_jitter == "the caller ran jitter_spherical first", i.e. the angles are clamped into the range of the cheap trig
+    if (rot_jitter) fast_phase1<VARIANT, DIM, true>(b1, b2, edge, r, &t);
+    else fast_phase1<VARIANT, DIM, false>(b1, b2, edge, r, &t);
     PlanarPair q;
     fast_planar<VARIANT, DIM>(r, q);
     if (!rot_jitter) { q.g_wg = q.g_hg = q.g_wp = q.g_hp = true; }
@@ -233,6 +235,15 @@ SPH_DEV void planar_to_spherical_grads(const LossFront& f, PlanarGrad gP, Planar
 template <int DIM, bool BWD, bool FAST>
 SPH_DEV float pair_loss(const float (&pred)[5], const float (&target)[5], int loss_mode, float eps, float* iou_out,
                         float (&gpred)[5], float (&gtarget)[5]) {
+    if (pair_has_nan<DIM>(pred, target)) {
+        // torch propagates a NaN coordinate into the loss element and, through autograd, into every gradient of the
+        // pair; the clamps / min / max on the way here would drop it and train on garbage
+        const float qnan = __builtin_nanf("");
+        if (iou_out) *iou_out = qnan;
+#pragma unroll
+        for (int k = 0; k < 5; k++) { gpred[k] = k < DIM ? qnan : 0.0f; gtarget[k] = k < DIM ? qnan : 0.0f; }
+        return qnan;
+    }
     float b1[5], b2[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) { b1[k] = pred[k]; b2[k] = target[k]; }
@@ -253,6 +264,15 @@ SPH_DEV float pair_loss(const float (&pred)[5], const float (&target)[5], int lo
     EdgeSet eA = edges_inside_grad(pax, pay, c, s, ic, is, hwa, hha, hwb, hhb, P.w, P.h, true);
     EdgeSet eB = edges_inside_grad(pbx, pby, c, -s, ic, -is, hwb, hhb, hwa, hha, T.w, T.h, false);
     float I = 0.5f * fmaxf(eA.area2 + eB.area2, 0.0f);
+    {   // near-parallel planar boxes (the two jitter steps cancelled: DESIGN.md §9): the value of the intersection comes
+        // from the first-order form; the boundary-transport gradient terms above stay (their relative error there is the
+        // integral's, a few percent at worst, on ~1e-4 of the pairs).  Wave-uniform guard: the common wave skips the code.
+        const bool near = fminf(fabsf(s), fabsf(c)) < kNearParallel;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (__ballot(near) != 0ull)
+#endif
+            if (near) I = fmaxf(near_parallel_inter(pax, pay, c, s, hwa, hha, hwb, hhb), 0.0f);
+    }
     float S1 = P.w * P.h, S2 = T.w * T.h;
     float U = S1 + S2 - I;
     float iou_raw = fdiv(I, U);

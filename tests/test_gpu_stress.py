@@ -97,9 +97,11 @@ def test_launchers_are_graph_capturable():
     assert float(captured[0].min()) > 0.8        # IoU(x, x) after the reference's jitter
 
 
-def test_robust_mode_fixes_jitter_cancellation_pairs():
-    """Pairs found by the 2 M-pair soak: the reference's jitter leaves their planar boxes parallel to ~1e-6 rad; the
-    default closed-form kernel is off by up to 2e-2 there (documented), 'robust' and 'reference' arithmetic are not."""
+def test_default_arithmetic_is_right_on_jitter_cancellation_pairs():
+    """Pairs found by the 2 M-pair soak: the reference's two jitter steps cancel and leave the planar boxes parallel to
+    ~1e-6 rad, where the plain fp32 boundary integral is off by up to 2e-2.  Such lanes are classified `rare` by
+    lean_stage1 and take the general form with the near-parallel safeguard: the DEFAULT arithmetic must be right on
+    them (round 1 asserted the opposite and offered an opt-in 'robust' mode; that name is still accepted)."""
     import torch
     import sph_retina_amd as S
     from oracle import oracle as O
@@ -117,15 +119,17 @@ def test_robust_mode_fixes_jitter_cancellation_pairs():
             got[mode] = np.abs(S.sph2pob_standard_iou(t1, t2, is_aligned=True).cpu().numpy() - tru)
             pw = S.sph2pob_standard_iou(t1, t2).cpu().numpy()
             assert np.abs(np.diag(pw) - S.sph2pob_standard_iou(t1, t2, is_aligned=True).cpu().numpy()).max() == 0
-        assert got['fast'].max() > 1e-3                      # the known corner of the default path
-        assert got['robust'].max() < 2e-5 and got['reference'].max() < 2e-5, got
-        # and robust == fast bit for bit away from the corner
+        assert got['fast'].max() < 2e-5 and got['robust'].max() < 2e-5 and got['reference'].max() < 2e-5, got
+        # the loss kernels carry the same safeguard: IoU-mode loss element = 1 - IoU on these pairs
+        S.set_arithmetic('fast')
+        le = S.Sph2PobIoULoss(mode='iou', reduction='none')(t1, t2).cpu().numpy()
+        assert np.abs((1.0 - le) - tru).max() < 2e-5, (1.0 - le, tru)
+        # 'robust' is an alias of the default now
         a = torch.from_numpy(O.generate_boxes(200000, 0)).cuda()
         b = torch.from_numpy(O.generate_boxes(200000, 1)).cuda()
-        S.set_arithmetic('fast')
         f = S.sph2pob_standard_iou(a, b, is_aligned=True)
         S.set_arithmetic('robust')
         r = S.sph2pob_standard_iou(a, b, is_aligned=True)
-        assert int((f != r).sum()) <= 60 and float((f - r).abs().max()) < 1e-3   # ~3e-4 of the overlapping pairs take the branch
+        assert torch.equal(f, r)
     finally:
         S.set_arithmetic(prev)
