@@ -74,52 +74,41 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_kernel(const float* __rest
     out[i] = pair_iou_sel<VARIANT, DIM, FAST>(x, y, mode, edge, angle);
 }
 
-// ---- dominant kernel: aligned IoU, closed-form core, three stages with wave-level compaction between them ----
+// ---- dominant kernel: aligned IoU, closed-form core, with wave-level compaction of the cull survivors ----
 // ~60 % of the benchmark distribution's pairs are culled exactly by the bounding-circle test of stage 0 (hardware
-// sin/cos, conservative margins); of the survivors another ~35 % are rejected exactly by the separating-axis test at
-// the end of stage 1 (accurate trig, bearings, A): only 26 % of the pairs overlap and only those need the clip.  A
-// naive `if (!culled) ...` leaves every wave running each later stage with 40 % / 26 % of its lanes.  Here each wave
-// walks 64-pair slices and keeps two LDS stacks: S1 takes the cull survivors' raw boxes, S2 the SAT survivors' planar
-// records (ballot + prefix rank => conflict-free consecutive slots, no atomics, no barriers: LDS operations of one
-// wave are in order).  A stage runs only when 64 records are available, i.e. on fully populated waves.  Rare lanes
-// (jitter decisions, acos floors, near-parallel boxes, NaN: lean_stage1) are finished in place by the general form.
-// The two stacks share one array and grow towards each other: S1 from slot 0 up, S2 from the last slot down; at any
-// time S1 <= 127 with S2 <= 63, or S1 <= 63 with S2 <= 127, so 192 slots suffice (7.7 KB per wave for BFoV: 5
-// workgroups per CU).  Leftovers of the 4 waves of a workgroup are merged once per stack at the end.
-// Stores: culled / separated pairs write 0 from their stage, survivors write from stage 2 (or the general form) by index.
-constexpr int kPipeSlots = 192;
+// sin/cos, conservative margins); only survivors pay for accurate trig and the clip.  A naive `if (!culled) ...`
+// leaves every wave running the later stages with ~40 % of its lanes.  Here each wave walks 64-pair slices, pushes the
+// survivors' raw boxes on its own LDS stack S1 (ballot + prefix rank => conflict-free consecutive slots, no atomics,
+// no barriers: LDS operations of one wave are in order), and runs stages 1 + 2 (lean_stage1 / lean_stage2: straight-
+// line code) only when 64 records are available, i.e. on fully populated waves.  Lanes that lean_stage1 classifies as
+// RARE (jitter decisions, acos floors, near-parallel boxes, NaN: ~0.7 % of the survivors, but 36 % of the survivor WAVES
+// hold one) are not finished in place — that made every third wave run the general form for one lane, +37 % kernel time
+// (profiles/r02b_ablation.log) — but deferred: their pair indices go on a second, index-only stack S3 and the general
+// form runs on them 64 at a time (or once per workgroup at the end), re-reading the boxes through L2.
+// Leftovers of the 4 waves of a workgroup are merged once per stack at the end.
+// Stores: culled / separated pairs write 0 from their stage, the others write from stage 2 or the general form by index.
+// (A third stage — a second record stack between the separating-axis test and the clip, so that the clip also runs on
+// full waves — was built and measured: 8.80 against 8.55 us per 1 M pairs; the 35 % idle clip lanes cost less than
+// the extra LDS round trip.  profiles/r02b_ablation.log.)
+constexpr int kQCap = 128;                    // per-wave stack capacity (<= 63 carried + 64 pushed)
 template <int DIM>
-struct PipeQueue {
-    static constexpr int kFields = DIM == 4 ? 9 : 10;   // S1: 2 * DIM raw coordinates; S2: the 9 floats of a LeanRec
-    float f[kFields][kPipeSlots];
-    int idx[kPipeSlots];
+struct WaveQueue {
+    float f[2 * DIM][kQCap];   // S1: raw (theta, phi, alpha, beta[, gamma]) of both boxes
+    int idx[kQCap];            // S1: pair index
+    int rare[2 * kQCap];       // S3: pair indices of deferred rare lanes (drained once per two slices: <= 63 + 128)
 };
-constexpr int pipe_lds_bytes(int dim) { return (kBlock / 64) * ((dim == 4 ? 9 : 10) + 1) * kPipeSlots * 4 + 64; }
+constexpr int pipe_lds_bytes(int dim) { return (kBlock / 64) * (2 * dim + 3) * kQCap * 4 + 64; }
 
 template <int DIM>
-__device__ __forceinline__ void s1_store(PipeQueue<DIM>& q, int slot, const float (&j1)[5], const float (&j2)[5], int i) {
+__device__ __forceinline__ void s1_store(WaveQueue<DIM>& q, int slot, const float (&j1)[5], const float (&j2)[5], int i) {
 #pragma unroll
     for (int k = 0; k < DIM; k++) { q.f[k][slot] = j1[k]; q.f[DIM + k][slot] = j2[k]; }
     q.idx[slot] = i;
 }
 template <int DIM>
-__device__ __forceinline__ int s1_load(const PipeQueue<DIM>& q, int slot, float (&j1)[5], float (&j2)[5]) {
+__device__ __forceinline__ int s1_load(const WaveQueue<DIM>& q, int slot, float (&j1)[5], float (&j2)[5]) {
 #pragma unroll
     for (int k = 0; k < 5; k++) { j1[k] = k < DIM ? q.f[k][slot] : 0.0f; j2[k] = k < DIM ? q.f[DIM + k][slot] : 0.0f; }
-    return q.idx[slot];
-}
-template <int DIM>
-__device__ __forceinline__ void s2_store(PipeQueue<DIM>& q, int j, const LeanRec& r, int i) {
-    const int slot = kPipeSlots - 1 - j;
-    q.f[0][slot] = r.A;  q.f[1][slot] = r.ca; q.f[2][slot] = r.sa; q.f[3][slot] = r.cb; q.f[4][slot] = r.sb;
-    q.f[5][slot] = r.wg; q.f[6][slot] = r.hg; q.f[7][slot] = r.wp; q.f[8][slot] = r.hp;
-    q.idx[slot] = i;
-}
-template <int DIM>
-__device__ __forceinline__ int s2_load(const PipeQueue<DIM>& q, int j, LeanRec& r) {
-    const int slot = kPipeSlots - 1 - j;
-    r.A = q.f[0][slot];  r.ca = q.f[1][slot]; r.sa = q.f[2][slot]; r.cb = q.f[3][slot]; r.sb = q.f[4][slot];
-    r.wg = q.f[5][slot]; r.hg = q.f[6][slot]; r.wp = q.f[7][slot]; r.hp = q.f[8][slot];
     return q.idx[slot];
 }
 __device__ __forceinline__ void wave_lds_fence() {
@@ -136,60 +125,56 @@ __device__ __forceinline__ void locate_leftover(int k, int c0, int c1, int c2, i
 // ARC: rbb_edge == 'arc' folded at compile time (the chord / tangent forms pull ocml's sinf / tanf argument reduction
 // into the cull and stage 1: 8 copies of ~100 instructions the common launch never executes)
 template <int VARIANT, int DIM, bool PREFETCH, bool ARC>
-__global__ __launch_bounds__(kBlock) void iou_aligned_pipe_kernel(const float* __restrict__ b1,
-                                                                 const float* __restrict__ b2,
-                                                                 float* __restrict__ out, int n, int mode,
-                                                                 int edge_arg) {
-    __shared__ PipeQueue<DIM> queues[kBlock / 64];
-    __shared__ int left1[kBlock / 64], left2[kBlock / 64];
+__global__ __launch_bounds__(kBlock, DIM == 4 ? 6 : 5) void iou_aligned_compact_kernel(const float* __restrict__ b1,
+                                                                    const float* __restrict__ b2,
+                                                                    float* __restrict__ out, int n, int mode,
+                                                                    int edge_arg) {
+    __shared__ WaveQueue<DIM> queues[kBlock / 64];
+    __shared__ int left1[kBlock / 64], left3[kBlock / 64];
     const int edge = ARC ? (int)EDGE_ARC : edge_arg;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    PipeQueue<DIM>& q = queues[wave];
+    WaveQueue<DIM>& q = queues[wave];
     const int nslices = (n + 63) >> 6;
     const int wave_global = blockIdx.x * (kBlock / 64) + wave, nwaves = gridDim.x * (kBlock / 64);
-    int c1 = 0, c2 = 0;  // wave-uniform stack heights
-    // stage 1 on one record per lane (taken from `src`'s S1), survivors pushed on this wave's own S2
-    auto stage1 = [&](const PipeQueue<DIM>& src, int slot, bool active) {
-        bool surv = false;
-        LeanRec rec;
+    int c1 = 0, c3 = 0;  // wave-uniform stack heights
+    // the general form on one deferred pair per lane
+    auto finish_rare = [&](int j, bool active) {
+        if (active) {
+            float u1[5], u2[5];
+            load_box<DIM>(b1, j, u1);
+            load_box<DIM>(b2, j, u2);
+            out[j] = fast_finish<VARIANT, DIM>(u1, u2, mode, edge);
+        }
+    };
+    // stages 1 + 2 on one S1 record per lane (taken from `src`); rare lanes are pushed on this wave's own S3
+    auto stage12 = [&](const WaveQueue<DIM>& src, int slot, bool active) {
+        bool rare = false;
         int j = 0;
         if (active) {
             float u1[5], u2[5];
             j = s1_load<DIM>(src, slot, u1, u2);
-            const int st = lean_stage1<VARIANT, DIM>(u1, u2, edge, rec);
-            if (st == LEAN_ZERO) out[j] = 0.0f;
-            else if (st == LEAN_RARE) out[j] = fast_finish<VARIANT, DIM>(u1, u2, mode, edge);
-            else surv = true;
-        }
-        const unsigned long long m = __ballot(surv);
-        if (surv) s2_store<DIM>(q, c2 + __popcll(m & ((1ull << lane) - 1ull)), rec, j);
-        c2 += __popcll(m);
-    };
-    auto stage2 = [&](const PipeQueue<DIM>& src, int j2, bool active) {
-        if (active) {
             LeanRec rec;
-            const int j = s2_load<DIM>(src, j2, rec);
-            out[j] = lean_stage2(rec, mode);
+            const int st = lean_stage1<VARIANT, DIM>(u1, u2, edge, rec);
+            if (st == LEAN_SURVIVOR) out[j] = lean_stage2(rec, mode);
+            else if (st == LEAN_ZERO) out[j] = 0.0f;
+            else rare = true;
+        }
+        const unsigned long long m = __ballot(rare);
+        if (m != 0ull) {   // wave-uniform
+            if (rare) q.rare[c3 + __popcll(m & ((1ull << lane) - 1ull))] = j;
+            c3 += __popcll(m);
         }
     };
-    // software prefetch: the next slice's boxes are in flight while this slice is computed (register double buffer)
-    float nx[5], ny[5];
-    {
-        const int i0 = wave_global * 64 + lane;
-        if (PREFETCH && wave_global < nslices && i0 < n) { load_box<DIM>(b1, i0, nx); load_box<DIM>(b2, i0, ny); }
-    }
-    for (int sl = wave_global; sl < nslices; sl += nwaves) {
-        const int i = sl * 64 + lane;
-        float x[5], y[5];
-        if (PREFETCH) {
-#pragma unroll
-            for (int k = 0; k < 5; k++) { x[k] = nx[k]; y[k] = ny[k]; }
-            const int sn = sl + nwaves, in = sn * 64 + lane;
-            if (sn < nslices && in < n) { load_box<DIM>(b1, in, nx); load_box<DIM>(b2, in, ny); }
-        } else if (i < n) {
-            load_box<DIM>(b1, i, x);
-            load_box<DIM>(b2, i, y);
+    auto drain_rare = [&]() {
+        while (c3 >= 64) {   // wave-uniform
+            c3 -= 64;
+            wave_lds_fence();
+            finish_rare(q.rare[c3 + lane], true);
         }
+    };
+    // one slice: cull, push the survivors, run stages 1 + 2 when a full wave of records is available
+    auto slice = [&](const float (&x)[5], const float (&y)[5], int sl) {
+        const int i = sl * 64 + lane;
         bool surv = false;
         if (i < n) {
             if (fast_cull<DIM>(x, y, edge)) out[i] = 0.0f;
@@ -201,16 +186,34 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_pipe_kernel(const float* _
         if (c1 >= 64) {  // wave-uniform
             c1 -= 64;
             wave_lds_fence();
-            stage1(q, c1 + lane, true);
-            if (c2 >= 64) {
-                c2 -= 64;
-                wave_lds_fence();
-                stage2(q, c2 + lane, true);
-            }
+            stage12(q, c1 + lane, true);
+        }
+    };
+    auto fetch = [&](int sl, float (&x)[5], float (&y)[5]) {
+        const int i = sl * 64 + lane;
+        if (sl < nslices && i < n) { load_box<DIM>(b1, i, x); load_box<DIM>(b2, i, y); }
+    };
+    if (PREFETCH) {
+        // software prefetch, two register sets used alternately (no copies): while a slice is computed the next one's
+        // boxes are in flight
+        float ax[5] = {0, 0, 0, 0, 0}, ay[5] = {0, 0, 0, 0, 0}, bx[5] = {0, 0, 0, 0, 0}, by[5] = {0, 0, 0, 0, 0};
+        fetch(wave_global, ax, ay);
+        for (int sl = wave_global; sl < nslices; sl += 2 * nwaves) {
+            fetch(sl + nwaves, bx, by);
+            slice(ax, ay, sl);
+            fetch(sl + 2 * nwaves, ax, ay);
+            if (sl + nwaves < nslices) slice(bx, by, sl + nwaves);
+            drain_rare();
+        }
+    } else {
+        for (int sl = wave_global; sl < nslices; sl += nwaves) {
+            float x[5] = {0, 0, 0, 0, 0}, y[5] = {0, 0, 0, 0, 0};
+            fetch(sl, x, y);
+            slice(x, y, sl);
+            drain_rare();
         }
     }
-    // merge the < 64 S1 leftovers of the four waves and run stage 1 on as few, as full waves as possible (a wave reads
-    // other waves' S1 slots [0, 63) and pushes on its own S2, slots >= 65: no overlap)
+    // merge the < 64 S1 leftovers of the four waves and finish them on as few, as full waves as possible
     if (lane == 0) left1[wave] = c1;
     __syncthreads();
     {
@@ -220,24 +223,20 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_pipe_kernel(const float* _
         if (wave * 64 < total) {
             int w, r;
             locate_leftover(k, a0, a1, a2, w, r);
-            stage1(queues[w], r, k < total);
-            if (c2 >= 64) {
-                c2 -= 64;
-                wave_lds_fence();
-                stage2(q, c2 + lane, true);
-            }
+            stage12(queues[w], r, k < total);
         }
     }
-    if (lane == 0) left2[wave] = c2;
+    // the same for the deferred rare lanes (<= 127 per wave here)
+    if (lane == 0) left3[wave] = c3;
     __syncthreads();
     {
-        const int a0 = left2[0], a1 = left2[1], a2 = left2[2], a3 = left2[3];
+        const int a0 = left3[0], a1 = left3[1], a2 = left3[2], a3 = left3[3];
         const int total = a0 + a1 + a2 + a3;
-        const int k = wave * 64 + lane;
-        if (wave * 64 < total) {
-            int w, r;
-            locate_leftover(k, a0, a1, a2, w, r);
-            stage2(queues[w], r, k < total);
+        for (int base = wave * 64; base < total; base += kBlock) {
+            const int k = base + lane;
+            int w = 0, r = 0;
+            if (k < total) locate_leftover(k, a0, a1, a2, w, r);
+            finish_rare(k < total ? queues[w].rare[r] : 0, k < total);
         }
     }
 }
@@ -246,16 +245,12 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_pipe_kernel(const float* _
 // One thread owns one column box (anchor); a workgroup covers 256 columns x up to 64 rows (GT).  Per-box cull
 // quantities are hoisted: rows live in LDS (broadcast reads), the column's in registers, so a culled pair costs
 // ~15 VALU instructions + one coalesced store of 0.  Cull survivors are (row, column) index pairs on the wave's S1
-// stack; stage 1 runs on 64 of them at a time (row box from LDS, column box re-read through L1/L2) and pushes the
-// separating-axis survivors' planar records on S2; stage 2 (the clip) again runs on fully populated waves — the same
-// three-stage scheme as iou_aligned_pipe_kernel, with the wave's own leftovers finished at the end (no merging:
-// a wave handles rows x 64 pairs, the leftover share is small).
+// stack; stages 1 + 2 run on 64 of them at a time (row box from LDS, column box re-read through L1/L2); rare lanes are
+// deferred on an index stack S3 exactly as in iou_aligned_compact_kernel and finished per wave at the end.
 constexpr int kPwRows = 64;
-constexpr int kPwSlots = 128;   // S1 and S2 separately (S1 is 8 bytes per slot)
 struct PairQueue {
-    int2 s1[kPwSlots];
-    float f[9][kPwSlots];
-    int2 s2[kPwSlots];
+    int2 s1[kQCap];
+    int2 s3[kQCap];
 };
 template <int VARIANT, int DIM>
 __global__ __launch_bounds__(kBlock) void iou_pairwise_compact_kernel(const float* __restrict__ b1, int m,
@@ -282,17 +277,16 @@ __global__ __launch_bounds__(kBlock) void iou_pairwise_compact_kernel(const floa
     if (valid) load_box<DIM>(b2, j, a);
     const CullBox ca = cull_box(a, edge);
     PairQueue& q = queues[wave];
-    int c1 = 0, c2 = 0;
-    auto stage2 = [&](int slot) {
-        LeanRec rec;
-        rec.A = q.f[0][slot];  rec.ca = q.f[1][slot]; rec.sa = q.f[2][slot]; rec.cb = q.f[3][slot]; rec.sb = q.f[4][slot];
-        rec.wg = q.f[5][slot]; rec.hg = q.f[6][slot]; rec.wp = q.f[7][slot]; rec.hp = q.f[8][slot];
-        const int2 e = q.s2[slot];
-        out[(int64_t)(r0 + e.x) * n + e.y] = lean_stage2(rec, mode);
+    int c1 = 0, c3 = 0;
+    auto finish_rare = [&](int2 e) {
+        float g[5], p[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) g[k] = row_raw[e.x][k];
+        load_box<DIM>(b2, e.y, p);
+        out[(int64_t)(r0 + e.x) * n + e.y] = fast_finish<VARIANT, DIM>(g, p, mode, edge);
     };
-    auto stage1 = [&](int slot, bool active) {
-        bool surv = false;
-        LeanRec rec;
+    auto stage12 = [&](int slot, bool active) {
+        bool rare = false;
         int2 e = make_int2(0, 0);
         if (active) {
             e = q.s1[slot];
@@ -300,24 +294,22 @@ __global__ __launch_bounds__(kBlock) void iou_pairwise_compact_kernel(const floa
 #pragma unroll
             for (int k = 0; k < 5; k++) g[k] = row_raw[e.x][k];
             load_box<DIM>(b2, e.y, p);
+            LeanRec rec;
             const int st = lean_stage1<VARIANT, DIM>(g, p, edge, rec);
             float* dst = out + (int64_t)(r0 + e.x) * n + e.y;
-            if (st == LEAN_ZERO) *dst = 0.0f;
-            else if (st == LEAN_RARE) *dst = fast_finish<VARIANT, DIM>(g, p, mode, edge);
-            else surv = true;
+            if (st == LEAN_SURVIVOR) *dst = lean_stage2(rec, mode);
+            else if (st == LEAN_ZERO) *dst = 0.0f;
+            else rare = true;
         }
-        const unsigned long long mk = __ballot(surv);
-        if (surv) {
-            const int s = c2 + __popcll(mk & ((1ull << lane) - 1ull));
-            q.f[0][s] = rec.A;  q.f[1][s] = rec.ca; q.f[2][s] = rec.sa; q.f[3][s] = rec.cb; q.f[4][s] = rec.sb;
-            q.f[5][s] = rec.wg; q.f[6][s] = rec.hg; q.f[7][s] = rec.wp; q.f[8][s] = rec.hp;
-            q.s2[s] = e;
-        }
-        c2 += __popcll(mk);
-        if (c2 >= 64) {
-            c2 -= 64;
-            wave_lds_fence();
-            stage2(c2 + lane);
+        const unsigned long long mk = __ballot(rare);
+        if (mk != 0ull) {
+            if (rare) q.s3[c3 + __popcll(mk & ((1ull << lane) - 1ull))] = e;
+            c3 += __popcll(mk);
+            if (c3 >= 64) {
+                c3 -= 64;
+                wave_lds_fence();
+                finish_rare(q.s3[c3 + lane]);
+            }
         }
     };
     for (int i = 0; i < rows; i++) {
@@ -333,13 +325,13 @@ __global__ __launch_bounds__(kBlock) void iou_pairwise_compact_kernel(const floa
         if (c1 >= 64) {
             c1 -= 64;
             wave_lds_fence();
-            stage1(c1 + lane, true);
+            stage12(c1 + lane, true);
         }
     }
     wave_lds_fence();
-    if (c1 > 0) stage1(lane, lane < c1);
+    if (c1 > 0) stage12(lane, lane < c1);
     wave_lds_fence();
-    if (lane < c2) stage2(lane);
+    if (lane < c3) finish_rare(q.s3[lane]);
 }
 
 // out[i*n + j]: consecutive lanes walk j (coalesced stores, b2 loads coalesced, b1 row is a broadcast).
@@ -791,12 +783,13 @@ struct AlignedLaunch {
         dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
         if (fast && V < 2 && angle == SPH2POB_ANGLE_EQUATOR && n < ((int64_t)1 << 31) - 64 && !g_no_compact) {
             // persistent-style grid.  Measured on MI355X (tools/sweep_slices.sh): every CU must hold the same number of
-            // workgroups (1 303 workgroups = 5.09 per CU take 12 % longer than 1 536 = 6 per CU); as many resident
-            // workgroups as the LDS allows (the two stacks: 5 per CU for BFoV, 4 for RBFoV); small launches want one
-            // slice per wave rather than full survivor stacks.  Hence: whole multiples of the CU count, at most the
-            // resident number per CU, at least one 64-pair slice per wave.
+            // workgroups (1 303 workgroups = 5.09 per CU take 12 % longer than 1 536 = 6 per CU); 6 per CU (24 waves per CU)
+            // is the best or within noise of the best from 125 k to 8 M pairs; small launches want one slice per wave
+            // rather than full survivor stacks.  Hence: whole multiples of the CU count, at most 6 per CU (and never
+            // more than the LDS admits), at least one 64-pair slice per wave.
             const int64_t kCUs = cu_count();
-            const int64_t resident = (160 * 1024) / pipe_lds_bytes(D);
+            int64_t resident = (160 * 1024) / pipe_lds_bytes(D);
+            if (resident > (D == 4 ? 6 : 5)) resident = D == 4 ? 6 : 5;   // the kernel's __launch_bounds__ (registers)
             int64_t slices = (n + 63) / 64;
             int64_t wgs = (slices + 3) / 4;
             if (g_slices_per_wave > 0) wgs = (slices + 4 * g_slices_per_wave - 1) / (4 * g_slices_per_wave);
@@ -804,7 +797,7 @@ struct AlignedLaunch {
             if (g_wgs_per_cu > 0) wgs = kCUs * g_wgs_per_cu;
             if (wgs < 1) wgs = 1;
             constexpr int VV = V >= 2 ? 0 : V;
-#define SPH_PIPE(PF, ARC) hipLaunchKernelGGL((iou_aligned_pipe_kernel<VV, D, PF, ARC>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge)
+#define SPH_PIPE(PF, ARC) hipLaunchKernelGGL((iou_aligned_compact_kernel<VV, D, PF, ARC>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge)
             if (edge == SPH2POB_EDGE_ARC) { if (g_prefetch) SPH_PIPE(true, true); else SPH_PIPE(false, true); }
             else { if (g_prefetch) SPH_PIPE(true, false); else SPH_PIPE(false, false); }
 #undef SPH_PIPE
