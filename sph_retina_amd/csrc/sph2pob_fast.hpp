@@ -256,7 +256,7 @@ SPH_DEV CullBox cull_box(const float (&b)[5], int edge) {
     float ph = min_nan(max_nan(b[1], 0.0f), 180.0f) * kRev;
     CullBox cb;
     cb.s = hw_sin_rev(ph);
-    cb.c = hw_cos_rev(ph);
+    cb.c = fmaf(b[4], 0.0f, hw_cos_rev(ph));   // a NaN / infinite gamma (0 for BFoV: folded) must not be culled either
     cb.th_rev = min_nan(max_nan(b[0], 0.0f), 360.0f) * kRev;
     cb.r = d > 0.0f ? 0.5f * d * fast_rsq(d) : __builtin_inff();   // d = NaN -> +inf: never culled
     return cb;
@@ -297,7 +297,8 @@ SPH_DEV bool fast_cull(const float (&g)[5], const float (&p)[5], int edge) {
     const float thg = min_nan(max_nan(g[0] * kRev, 0.0f), 1.0f), thp = min_nan(max_nan(p[0] * kRev, 0.0f), 1.0f);
     const float u = hw_cos_rev(phg - php), v = hw_cos_rev(phg + php);
     const float cD = hw_cos_rev(thp - thg);
-    const float C = 0.5f * ((u + v) + (u - v) * cD);
+    float C = 0.5f * ((u + v) + (u - v) * cD);
+    if (DIM == 5) C = fmaf(g[4] + p[4], 0.0f, C);   // a NaN / infinite gamma must not be culled either
     return (R2 < 8.9f) & (C < cosR_lb - 1e-4f);
 }
 
@@ -449,102 +450,55 @@ SPH_DEV void fast_planar(const FastRec& r, PlanarPair& o) {
     o.wg = wg; o.hg = hg; o.wp = wp; o.hp = hp;
 }
 
-// Twice the intersection area from the planar pair: the boundary integral, or — per lane, when `robust` — the
-// first-order near-parallel form.
-SPH_DEV float planar_area2(const PlanarPair& q, float c, float s, bool robust) {
-#pragma clang fp contract(fast)
-    const float kBig = 1e18f;
-    float ic = fminf(fmaxf(fast_rcp(c), -kBig), kBig), is = fminf(fmaxf(fast_rcp(s), -kBig), kBig);
-    float aic = fabsf(ic), ais = fabsf(is);
-    float hwa = 0.5f * q.wg, hha = 0.5f * q.hg, hwb = 0.5f * q.wp, hhb = 0.5f * q.hp;
-    float pax = -(q.dx * q.cb + q.dy * q.sb), pay = -(q.dy * q.cb - q.dx * q.sb);
-    float pbx = q.dx * q.ca + q.dy * q.sa, pby = q.dy * q.ca - q.dx * q.sa;
-    float t2 = edges_inside3(pax, pay, c, s, ic, is, aic, ais, hwa, hha, hwb, hhb, q.wg, q.hg, true) +
-               edges_inside3(pbx, pby, c, -s, ic, -is, aic, ais, hwb, hhb, hwa, hha, q.wp, q.hp, false);
-    if (robust) {
-        const float alt = 2.0f * near_parallel_inter(pax, pay, c, s, hwa, hha, hwb, hhb);
-        t2 = fminf(fabsf(s), fabsf(c)) < kNearParallel ? alt : t2;
-    }
-    return t2;
-}
-// Phase 2 (general form): planar boxes with every rare branch of the reference (acos floors, both jitters' decisions,
-// angle clamps), then the boundary-integral intersection and the IoU.  Pairs left nearly parallel by a cancellation of
-// the reference's two jitter steps are evaluated with near_parallel_inter.  This is the slow, complete
-// path: the kernels send only the rare lanes through it (lean_stage1 below decides which), so its extra branches cost
-// the common pair nothing.
-template <int VARIANT, int DIM>
-SPH_DEV float fast_phase2(const FastRec& r, int mode) {
-#pragma clang fp contract(fast)
-    PlanarPair q;
-    fast_planar<VARIANT, DIM>(r, q);
-    float c = q.ca * q.cb + q.sa * q.sb, s = q.sa * q.cb - q.ca * q.sb;
-    const bool near = fminf(fabsf(s), fabsf(c)) < kNearParallel;
-    float t2 = planar_area2(q, c, s, near);
-    float inter = 0.5f * fmaxf(t2, 0.0f);
-    float a1 = q.wg * q.hg, a2 = q.wp * q.hp;
-    float base = mode == MODE_IOU ? (a1 + a2 - inter) : a1;
-    float rb = fast_rcp(base);
-    rb = rb * (2.0f - base * rb);  // one Newton step: ~0.5 ulp quotient without the IEEE divide expansion
-    float iou = inter * rb;
-    return fminf(fmaxf(iou, 0.0f), 1.0f);
-}
+// "any lane of the wave": the rare branches of the finishing stage are guarded wave-uniformly, so a wave none of whose
+// lanes needs a branch skips its code with one scalar branch instead of executing it under an empty mask or paying
+// for always-on selects.  On the host (unit tests) a "wave" is one pair.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SPH_ANY_LANE(cond) (__ballot(cond) != 0ull)
+#else
+#define SPH_ANY_LANE(cond) (cond)
+#endif
 
-// Spherical jitter + stages 1 + 2 for one pair, general form.  A NaN coordinate gives NaN, as the reference's
-// torch.clamp chain does (sph_iou_api.py:86, :244-260) — v_med3 / fmin / fmax on the way would otherwise drop it.
-template <int VARIANT, int DIM>
-SPH_DEV float fast_finish(const float (&in1)[5], const float (&in2)[5], int mode, int edge) {
-    if (pair_has_nan<DIM>(in1, in2)) return __builtin_nanf("");
-    float j1[5], j2[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) { j1[k] = in1[k]; j2[k] = in2[k]; }
-    jitter_spherical<DIM>(j1, j2);
-    FastRec r;
-    if (fast_phase1<VARIANT, DIM>(j1, j2, edge, r) == FAST_ZERO) return 0.0f;
-    return fast_phase2<VARIANT, DIM>(r, mode);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Lean pipeline (the common pair).  The compacting kernels run three stages with an LDS stack between them:
-//   stage 0  fast_cull / cull_pair       all pairs       bounding circles, hardware trig                  ~60 % leave
-//   stage 1  lean_stage1                 cull survivors  jitter clamps, accurate trig, bearings, A, exact
-//                                                        separating-axis test; classifies the lane          ~35 % leave
-//   stage 2  lean_stage2                 SAT survivors   the 8-edge boundary integral and the IoU — straight-line code
-// A lane is RARE when any branch of the general form could fire for it: a NaN, the spherical jitter's `similar`, an
-// acos floor (|sin a| < 4.88e-4, A < ~1e-3), the rotated jitter's `similar` / `close` decisions (which need real
-// angles), its size clamps, |gamma| > 3.1, or planar boxes within kNearParallel of parallel / perpendicular.  Rare lanes
-// (~1e-3 of the benchmark distribution) are finished in place by fast_finish; for every other lane the general form
-// would take none of its branches and compute exactly what stages 1 + 2 compute.
+// Spherical jitter + stages 1 + 2 for one pair that survived the cull: clamp(IoU, 0, 1).
 //
-// The SAT is exact in the sense of stage 0: it only rejects pairs whose planar rectangles are disjoint in the
-// reference's own (fp32-noisy, jittered) evaluation, for which the reference returns exactly 0.  Margins: the two
-// rectangles' relative position is uncertain by < 1.75e-3 (both jitters' shifts and growth, the reference's rounding
-// of A — the bound stage 0 uses), every angle by < 5e-3 rad (rotated jitter <= 3.1e-3, the reference's acos(clamp(.))
-// noise and floors <= 1e-3); a rotation by delta moves a projected extent by <= delta * (A + w + h) of the boxes
-// involved.  m = 2e-3 + 5e-3 * (A + w_g + h_g + w_p + h_p) covers both on all four axes.
-struct LeanRec { float A, ca, sa, cb, sb, wg, hg, wp, hp; };
-enum : int { LEAN_ZERO = 0, LEAN_SURVIVOR = 1, LEAN_RARE = 2 };
-
+// This is fast_phase1 + fast_planar + planar_area2 fused into one function whose COMMON path is straight-line code:
+// everything the reference only does for a few pairs in a thousand — the spherical jitter's shift, the acos floors,
+// the rotated jitter's decisions on real angles (2 atan2) and its bumps, the out-of-range gamma clamp, the
+// near-parallel safeguard — sits behind a wave-uniform guard.  Measured against the alternatives on MI355X
+// (profiles/r02b_ablation_*.log): always-on selects (round 1) 9.0 us per 1 M pairs; a lean path with rare
+// lanes re-run by the general form in place 12.1 us (0.7 % of the lanes, but every third wave holds one); the same
+// deferred to an index stack and finished per workgroup 11.0 us (one latency-bound pass per workgroup at the tail);
+// a separating-axis reject + second record stack in front of the clip 8.8 us with rare lanes dropped.
+// A NaN coordinate gives NaN, as the reference's torch.clamp chain does (sph_iou_api.py:86, :244-260).
 template <int VARIANT, int DIM>
-SPH_DEV int lean_stage1(const float (&in1)[5], const float (&in2)[5], int edge, LeanRec& o) {
+SPH_DEV float lean_finish(const float (&in1)[5], const float (&in2)[5], int mode, int edge) {
 #pragma clang fp contract(fast)
-    const float eps = (float)kEpsS, eps2 = (float)(2 * kEpsS);
-    bool rare = pair_has_nan<DIM>(in1, in2);
+    const float e = (float)kEpsS, e2 = (float)(2 * kEpsS), ea = (float)kEpsA;
+    const bool bad = pair_has_nan<DIM>(in1, in2);
+    // ---- jitter_spherical (sph_iou_api.py:244-260): shift only where `similar`, clamps always ----
+    float x1[5], x2[5];
+    bool similar = false;
 #pragma unroll
-    for (int k = 0; k < DIM; k++) rare |= fabsf(in1[k] - in2[k]) < eps;   // jitter_spherical's `similar`
-    // jitter_spherical without the shift (not similar): the clamps (sph_iou_api.py:251-258)
-    const float th1 = clampf(in1[0], eps2, (float)(360.0 - kEpsS)), th2 = clampf(in2[0], eps, (float)(360.0 - 2 * kEpsS));
-    const float ph1 = clampf(in1[1], eps2, (float)(180.0 - kEpsS)), ph2 = clampf(in2[1], eps, (float)(180.0 - 2 * kEpsS));
-    const float al1 = clampf(in1[2], eps2, (float)(180.0 - kEpsS)), al2 = clampf(in2[2], eps, (float)(180.0 - 2 * kEpsS));
-    const float be1 = clampf(in1[3], eps2, (float)(180.0 - kEpsS)), be2 = clampf(in2[3], eps, (float)(180.0 - 2 * kEpsS));
-    float ga1 = 0.0f, ga2 = 0.0f;
-    if (DIM == 5) {
-        ga1 = in1[4];
-        ga2 = clampf(in2[4], (float)(-360.0 + 2 * kEpsS), (float)(360.0 - 2 * kEpsS));
+    for (int k = 0; k < 5; k++) { x1[k] = in1[k]; x2[k] = in2[k]; }
+#pragma unroll
+    for (int k = 0; k < DIM; k++) similar |= fabsf(in1[k] - in2[k]) < e;
+    if (SPH_ANY_LANE(similar)) {
+        const float sh1 = similar ? e2 : 0.0f, sh2 = similar ? e : 0.0f;  // x - 0 == x exactly
+#pragma unroll
+        for (int k = 0; k < DIM; k++) { x1[k] = x1[k] - sh1; x2[k] = x2[k] + sh2; }
     }
-    // degrees -> radians with the reference's rounding, as fast_phase1
-    const float thg = th1 * kDeg2Rad, phg = ph1 * kDeg2Rad, thp = th2 * kDeg2Rad, php = ph2 * kDeg2Rad;
-    const float wg = edge_length(al1 * kDeg2Rad, edge), hg = edge_length(be1 * kDeg2Rad, edge);
-    const float wp = edge_length(al2 * kDeg2Rad, edge), hp = edge_length(be2 * kDeg2Rad, edge);
+    x1[0] = clampf(x1[0], e2, (float)(360.0 - kEpsS));
+    x2[0] = clampf(x2[0], e, (float)(360.0 - 2 * kEpsS));
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+        x1[k] = clampf(x1[k], e2, (float)(180.0 - kEpsS));
+        x2[k] = clampf(x2[k], e, (float)(180.0 - 2 * kEpsS));
+    }
+    if (DIM == 5) x2[4] = clampf(x2[4], (float)(-360.0 + 2 * kEpsS), (float)(360.0 - 2 * kEpsS));  // the two clamps of :256-258
+    // ---- stage 1 (fast_phase1): accurate trig on the jittered boxes, bearing numerators ----
+    const float thg = x1[0] * kDeg2Rad, phg = x1[1] * kDeg2Rad, thp = x2[0] * kDeg2Rad, php = x2[1] * kDeg2Rad;
+    float wg = edge_length(x1[2] * kDeg2Rad, edge), hg = edge_length(x1[3] * kDeg2Rad, edge);
+    float wp = edge_length(x2[2] * kDeg2Rad, edge), hp = edge_length(x2[3] * kDeg2Rad, edge);
     float sg, cg, sp, cp, sD, h2;
     sincos_colat(phg, sg, cg);
     sincos_colat(php, sp, cp);
@@ -553,78 +507,125 @@ SPH_DEV int lean_stage1(const float (&in1)[5], const float (&in2)[5], int edge, 
     const float N = q - sp * cg * h2, D = -sp * sD;
     const float Np = q + sg * cp * h2, Dp = -sg * sD;
     const float C = (cg * cp + sg * sp) - sg * sp * h2;
+    // ---- planar boxes as (cos, sin) (fast_planar) ----
     const float S2 = N * N + D * D;
     const float iS = fast_rsq(S2);
-    // A >= sin A > 1.05e-3 keeps clear of the acos floors (9.77e-4 standard / 4.88e-4 efficient), of the rotated
-    // jitter's `A < eps` and of the undefined bearing of coincident centres; antipodal centres (S2 ~ 0 too) go the same way
-    rare |= !(S2 > 1.1e-6f);
-    const float A = atan2_r(S2 * iS, C);
+    float A = atan2_r(S2 * iS, C);
+    A = fmaxf(A, VARIANT == VARIANT_STANDARD ? 2.0f * kMinAng : kMinAng);
     float ca = D * iS, sa = N * iS, cb = Dp * iS, sb = Np * iS;
+    if (SPH_ANY_LANE(!(S2 > 1e-30f))) {   // exactly coincident / antipodal centres: bearing undefined, convention a = pi/2
+        if (!(S2 > 1e-30f)) { ca = 0.0f; sa = 1.0f; cb = 0.0f; sb = 1.0f; }
+    }
+    float ga = 0.0f, gb = 0.0f;
     if (DIM == 5) {
-        const float ga = ga1 * kDeg2Rad, gb = ga2 * kDeg2Rad;
-        rare |= (fabsf(ga) > 3.1f) | (fabsf(gb) > 3.1f);
-        if (VARIANT == VARIANT_EFFICIENT) rare |= (fabsf(sa) < kMinAng) | (fabsf(sb) < kMinAng);   // floor, then a -= gamma
+        ga = x1[4] * kDeg2Rad;
+        gb = x2[4] * kDeg2Rad;
         float sga, cga, sgb, cgb;
         sincos_r(ga, sga, cga);
         sincos_r(gb, sgb, cgb);
+        if (VARIANT == VARIANT_EFFICIENT) {  // floor, then a -= gamma
+            if (SPH_ANY_LANE((fabsf(sa) < kMinAng) | (fabsf(sb) < kMinAng))) { angle_floor(ca, sa); angle_floor(cb, sb); }
+        }
         rot(ca, sa, cga, -sga);
         rot(cb, sb, cgb, -sgb);
-        if (VARIANT == VARIANT_STANDARD) rare |= (fabsf(sa) < kMinAng) | (fabsf(sb) < kMinAng);    // d rotated first
+        if (VARIANT == VARIANT_STANDARD) {   // d rotated first
+            if (SPH_ANY_LANE((fabsf(sa) < kMinAng) | (fabsf(sb) < kMinAng))) { angle_floor(ca, sa); angle_floor(cb, sb); }
+        }
     } else {
-        rare |= (fabsf(sa) < kMinAng) | (fabsf(sb) < kMinAng);
+        if (SPH_ANY_LANE((fabsf(sa) < kMinAng) | (fabsf(sb) < kMinAng))) { angle_floor(ca, sa); angle_floor(cb, sb); }
     }
-    const float c = ca * cb + sa * sb, s = sa * cb - ca * sb;   // cos / sin of (a_g - a_p)
-    const float as = fabsf(s), ac = fabsf(c);
-    // rotated jitter: `similar` on sizes, the angle decisions' candidate range, the size clamps; near-parallel boxes
-    rare |= (fabsf(wg - wp) < eps) | (fabsf(hg - hp) < eps);
-    rare |= (c > 0.5f) & (as < 2.0e-3f);
-    rare |= fminf(as, ac) < kNearParallel;
-    rare |= (fminf(wg, hg) < (float)(2 * kEpsA / 10)) | (fminf(wp, hp) < (float)(kEpsA / 10));
-    if (rare) return LEAN_RARE;
-    // separating-axis test on the four edge normals: p's centre in g's frame is (A ca, -A sa), g's centre in p's frame
-    // (-A cb, A sb); half extents of the other box projected with (|c|, |s|)
-    const float m2 = 2.0f * (2.0e-3f + 5.0e-3f * (A + ((wg + hg) + (wp + hp))));   // margin, doubled like the extents
-    const float ex_g = wg + (ac * wp + as * hp) + m2, ey_g = hg + (as * wp + ac * hp) + m2;
-    const float ex_p = wp + (ac * wg + as * hg) + m2, ey_p = hp + (as * wg + ac * hg) + m2;
-    const float A2 = A + A;
-    const bool apart = (A2 * fabsf(ca) > ex_g) | (A2 * fabsf(sa) > ey_g) | (A2 * fabsf(cb) > ex_p) | (A2 * fabsf(sb) > ey_p);
-    if (apart) return LEAN_ZERO;
-    o.A = A; o.ca = ca; o.sa = sa; o.cb = cb; o.sb = sb; o.wg = wg; o.hg = hg; o.wp = wp; o.hp = hp;
-    return LEAN_SURVIVOR;
-}
-
-// Stage 2 of the lean pipeline: boundary integral + IoU of a non-rare pair (P at the origin, T at (A, 0); no jitter
-// branch fired, no clamp is active, |sin|, |cos| of the relative angle >= kNearParallel so the reciprocals need no
-// clamping).  Same arithmetic as fast_phase2 executes for such a lane.
-SPH_DEV float lean_stage2(const LeanRec& r, int mode) {
-#pragma clang fp contract(fast)
-    const float c = r.ca * r.cb + r.sa * r.sb, s = r.sa * r.cb - r.ca * r.sb;
-    const float ic = fast_rcp(c), is = fast_rcp(s);
+    // ---- rotated jitter (sph_iou_api.py:222-242) on (x, w, h, a); its decisions need real angles only when the two
+    // angles are within ~1.8e-3 of each other modulo 2 pi ----
+    float c = ca * cb + sa * sb, s = sa * cb - ca * sb;  // cos / sin of (a_g - a_p)
+    bool sim = (A < e) | (fabsf(wg - wp) < e) | (fabsf(hg - hp) < e);
+    bool close = false;
+    const bool cand = (c > 0.5f) & (fabsf(s) < 2.0e-3f);
+    if (SPH_ANY_LANE(cand)) {
+        if (cand) {
+            float a1, a2;
+            if (DIM == 5 && VARIANT == VARIANT_EFFICIENT) {  // a = floor(atan2(N, D)) - gamma, not wrapped
+                float c1 = D * iS, s1 = N * iS, c2 = Dp * iS, s2 = Np * iS;
+                if (!(S2 > 1e-30f)) { c1 = 0.0f; s1 = 1.0f; c2 = 0.0f; s2 = 1.0f; }
+                angle_floor(c1, s1);
+                angle_floor(c2, s2);
+                a1 = atan2_r(s1, c1) - ga;
+                a2 = atan2_r(s2, c2) - gb;
+            } else {
+                a1 = atan2_r(sa, ca);
+                a2 = atan2_r(sb, cb);
+            }
+            sim |= fabsf(a1 - a2) < e;
+            if (sim) { a1 += e; a2 += (float)(5 * kEpsS); }
+            close = fabsf(a1 - a2) < ea;
+        }
+    }
+    float dx = A, dy = 0.0f;
+    if (SPH_ANY_LANE(sim | close)) {   // constant rotations of (cos, sin) instead of new trig
+        if (sim) {
+            dx += e; dy += e;  // (x, y) += (e, e) vs (2e, 2e)
+            wg += (float)(2 * kEpsS); hg += (float)(2 * kEpsS); wp += e; hp += e;
+            rot(ca, sa, (float)0.99999999237921, (float)1.2345678e-4);    // cos/sin(e)
+            rot(cb, sb, (float)0.99999980948025, (float)6.172838610e-4);  // cos/sin(5e)
+        }
+        if (close) {
+            rot(ca, sa, (float)0.99999923792122, (float)1.2345674864e-3);  // cos/sin(ea)
+            rot(cb, sb, (float)0.99999695168547, (float)2.4691330913e-3);  // cos/sin(2ea)
+        }
+        c = ca * cb + sa * sb;
+        s = sa * cb - ca * sb;
+    }
+    wg = fmaxf(wg, (float)(2 * kEpsA / 10)); hg = fmaxf(hg, (float)(2 * kEpsA / 10));
+    wp = fmaxf(wp, (float)(kEpsA / 10));     hp = fmaxf(hp, (float)(kEpsA / 10));
+    if (DIM == 5) {
+        const bool wide = (fabsf(ga) > 3.1f) | (fabsf(gb) > 3.1f);
+        if (SPH_ANY_LANE(wide)) {
+            if (wide) {
+                // |gamma| beyond 177 deg (outside any coder's range): the rotated jitter's angle clamp to
+                // [-2pi + 2ea, 2pi - ea] / [-2pi + ea, 2pi - 2ea] (sph_iou_api.py:239-240) may act on a = atan2(.) - gamma
+                const float twopi = 6.283185307179586f;
+                float a1 = atan2_r(sa, ca), a2 = atan2_r(sb, cb);  // wrapped representatives
+                if (VARIANT == VARIANT_EFFICIENT) {                // un-wrap to the reference's real value (|a| < 3*pi)
+                    a1 += twopi * rintf((-ga - a1) / twopi);
+                    a2 += twopi * rintf((-gb - a2) / twopi);
+                }
+                const float k1 = fminf(fmaxf(a1, -twopi + 2.0f * ea), twopi - ea), k2 = fminf(fmaxf(a2, -twopi + ea), twopi - 2.0f * ea);
+                if (k1 != a1 || k2 != a2) {
+                    sincos_r(k1 - twopi * rintf(k1 / twopi), sa, ca);
+                    sincos_r(k2 - twopi * rintf(k2 / twopi), sb, cb);
+                    c = ca * cb + sa * sb;
+                    s = sa * cb - ca * sb;
+                }
+            }
+        }
+    }
+    // ---- stage 2: boundary integral of the two rectangles (P at the origin, T at (dx, dy)) ----
+    const float kBig = 1e18f;
+    const float ic = fminf(fmaxf(fast_rcp(c), -kBig), kBig), is = fminf(fmaxf(fast_rcp(s), -kBig), kBig);
     const float aic = fabsf(ic), ais = fabsf(is);
-    const float hwa = 0.5f * r.wg, hha = 0.5f * r.hg, hwb = 0.5f * r.wp, hhb = 0.5f * r.hp;
-    const float pax = -(r.A * r.cb), pay = r.A * r.sb;
-    const float pbx = r.A * r.ca, pby = -(r.A * r.sa);
-    const float t2 = edges_inside3(pax, pay, c, s, ic, is, aic, ais, hwa, hha, hwb, hhb, r.wg, r.hg, true) +
-                     edges_inside3(pbx, pby, c, -s, ic, -is, aic, ais, hwb, hhb, hwa, hha, r.wp, r.hp, false);
+    const float hwa = 0.5f * wg, hha = 0.5f * hg, hwb = 0.5f * wp, hhb = 0.5f * hp;
+    const float pax = -(dx * cb + dy * sb), pay = -(dy * cb - dx * sb);
+    const float pbx = dx * ca + dy * sa, pby = dy * ca - dx * sa;
+    float t2 = edges_inside3(pax, pay, c, s, ic, is, aic, ais, hwa, hha, hwb, hhb, wg, hg, true) +
+               edges_inside3(pbx, pby, c, -s, ic, -is, aic, ais, hwb, hhb, hwa, hha, wp, hp, false);
+    const bool near = fminf(fabsf(s), fabsf(c)) < kNearParallel;   // the two jitter steps cancelled: DESIGN.md §9
+    if (SPH_ANY_LANE(near)) {
+        if (near) t2 = 2.0f * near_parallel_inter(pax, pay, c, s, hwa, hha, hwb, hhb);
+    }
     const float inter = 0.5f * fmaxf(t2, 0.0f);
-    const float a1 = r.wg * r.hg, a2 = r.wp * r.hp;
+    const float a1 = wg * hg, a2 = wp * hp;
     const float base = mode == MODE_IOU ? (a1 + a2 - inter) : a1;
     float rb = fast_rcp(base);
-    rb = rb * (2.0f - base * rb);
-    const float iou = inter * rb;
-    return fminf(fmaxf(iou, 0.0f), 1.0f);
+    rb = rb * (2.0f - base * rb);  // one Newton step: ~0.5 ulp quotient without the IEEE divide expansion
+    const float iou = fminf(fmaxf(inter * rb, 0.0f), 1.0f);
+    return bad ? __builtin_nanf("") : iou;
 }
 
-// One pair through the lean pipeline without compaction (the one-lane-per-pair kernels, NMS rows, host tests): the
-// same classification and the same arithmetic per class as the compacting kernels, hence bit-identical results.
+// VARIANT: 0 standard, 1 efficient.  Returns clamp(IoU, 0, 1) of one pair (one-lane-per-pair kernels, NMS rows, host
+// tests): the compacting kernels run exactly these two functions, hence bit-identical results everywhere.
 template <int VARIANT, int DIM>
 SPH_DEV float pair_iou_fast(const float (&in1)[5], const float (&in2)[5], int mode, int edge) {
     if (fast_cull<DIM>(in1, in2, edge)) return 0.0f;
-    LeanRec r;
-    const int st = lean_stage1<VARIANT, DIM>(in1, in2, edge, r);
-    if (st == LEAN_ZERO) return 0.0f;
-    if (st == LEAN_RARE) return fast_finish<VARIANT, DIM>(in1, in2, mode, edge);
-    return lean_stage2(r, mode);
+    return lean_finish<VARIANT, DIM>(in1, in2, mode, edge);
 }
 
 }  // namespace sph2pob

@@ -76,37 +76,34 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_kernel(const float* __rest
 
 // ---- dominant kernel: aligned IoU, closed-form core, with wave-level compaction of the cull survivors ----
 // ~60 % of the benchmark distribution's pairs are culled exactly by the bounding-circle test of stage 0 (hardware
-// sin/cos, conservative margins); only survivors pay for accurate trig and the clip.  A naive `if (!culled) ...`
-// leaves every wave running the later stages with ~40 % of its lanes.  Here each wave walks 64-pair slices, pushes the
-// survivors' raw boxes on its own LDS stack S1 (ballot + prefix rank => conflict-free consecutive slots, no atomics,
-// no barriers: LDS operations of one wave are in order), and runs stages 1 + 2 (lean_stage1 / lean_stage2: straight-
-// line code) only when 64 records are available, i.e. on fully populated waves.  Lanes that lean_stage1 classifies as
-// RARE (jitter decisions, acos floors, near-parallel boxes, NaN: ~0.7 % of the survivors, but 36 % of the survivor WAVES
-// hold one) are not finished in place — that made every third wave run the general form for one lane, +37 % kernel time
-// (profiles/r02b_ablation.log) — but deferred: their pair indices go on a second, index-only stack S3 and the general
-// form runs on them 64 at a time (or once per workgroup at the end), re-reading the boxes through L2.
-// Leftovers of the 4 waves of a workgroup are merged once per stack at the end.
-// Stores: culled / separated pairs write 0 from their stage, the others write from stage 2 or the general form by index.
-// (A third stage — a second record stack between the separating-axis test and the clip, so that the clip also runs on
-// full waves — was built and measured: 8.80 against 8.55 us per 1 M pairs; the 35 % idle clip lanes cost less than
-// the extra LDS round trip.  profiles/r02b_ablation.log.)
+// sin/cos, conservative margins); only survivors pay for accurate trig and the clip.  A naive `if (!culled) finish`
+// leaves every wave running the finishing stage with ~40 % of its lanes.  Here each wave walks 64-pair slices, pushes
+// the survivors' raw boxes on its own LDS stack (ballot + prefix rank => conflict-free consecutive slots, no atomics,
+// no barriers: LDS operations of one wave are in order), and runs lean_finish only when 64 records are available, i.e.
+// on fully populated waves.  Leftovers of the 4 waves of a workgroup are merged once at the end.
+// Stores: culled pairs write 0 from stage 0, survivors write from the finishing stage by index.
+// Variants built and measured on MI355X this round (1 M pairs; profiles/r02b_ablation_*.log):
+//   * a separating-axis reject after stage 1 + a second record stack so that the clip too runs on full waves (only
+//     26 % of the pairs overlap, 40 % pass the cull): 8.80 us against 8.55 us without the second stack — the 35 % idle
+//     clip lanes cost less than the extra LDS round trip and the longer per-wave dependency chain;
+//   * rare lanes (jitter decisions, floors, near-parallel: 0.7 % of the survivors) re-run by a general form in place
+//     12.1 us, deferred to an index stack and finished once per workgroup 11.0 us — hence lean_finish's guarded blocks.
 constexpr int kQCap = 128;                    // per-wave stack capacity (<= 63 carried + 64 pushed)
 template <int DIM>
 struct WaveQueue {
-    float f[2 * DIM][kQCap];   // S1: raw (theta, phi, alpha, beta[, gamma]) of both boxes
-    int idx[kQCap];            // S1: pair index
-    int rare[2 * kQCap];       // S3: pair indices of deferred rare lanes (drained once per two slices: <= 63 + 128)
+    float f[2 * DIM][kQCap];   // raw (theta, phi, alpha, beta[, gamma]) of both boxes
+    int idx[kQCap];            // pair index
 };
-constexpr int pipe_lds_bytes(int dim) { return (kBlock / 64) * (2 * dim + 3) * kQCap * 4 + 64; }
+constexpr int queue_lds_bytes(int dim) { return (kBlock / 64) * (2 * dim + 1) * kQCap * 4 + 64; }
 
 template <int DIM>
-__device__ __forceinline__ void s1_store(WaveQueue<DIM>& q, int slot, const float (&j1)[5], const float (&j2)[5], int i) {
+__device__ __forceinline__ void queue_store(WaveQueue<DIM>& q, int slot, const float (&j1)[5], const float (&j2)[5], int i) {
 #pragma unroll
     for (int k = 0; k < DIM; k++) { q.f[k][slot] = j1[k]; q.f[DIM + k][slot] = j2[k]; }
     q.idx[slot] = i;
 }
 template <int DIM>
-__device__ __forceinline__ int s1_load(const WaveQueue<DIM>& q, int slot, float (&j1)[5], float (&j2)[5]) {
+__device__ __forceinline__ int queue_load(const WaveQueue<DIM>& q, int slot, float (&j1)[5], float (&j2)[5]) {
 #pragma unroll
     for (int k = 0; k < 5; k++) { j1[k] = k < DIM ? q.f[k][slot] : 0.0f; j2[k] = k < DIM ? q.f[DIM + k][slot] : 0.0f; }
     return q.idx[slot];
@@ -115,64 +112,23 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-// position of the k-th leftover record in the concatenation of the four waves' stacks: (wave, index in its stack)
-__device__ __forceinline__ void locate_leftover(int k, int c0, int c1, int c2, int& w, int& r) {
-    w = 0;
-    if (k >= c0) { k -= c0; w = 1; if (k >= c1) { k -= c1; w = 2; if (k >= c2) { k -= c2; w = 3; } } }
-    r = k;
-}
 
 // ARC: rbb_edge == 'arc' folded at compile time (the chord / tangent forms pull ocml's sinf / tanf argument reduction
-// into the cull and stage 1: 8 copies of ~100 instructions the common launch never executes)
+// into the cull and the finishing stage: 8 copies of ~100 instructions the common launch never executes)
 template <int VARIANT, int DIM, bool PREFETCH, bool ARC>
-__global__ __launch_bounds__(kBlock, DIM == 4 ? 6 : 5) void iou_aligned_compact_kernel(const float* __restrict__ b1,
-                                                                    const float* __restrict__ b2,
-                                                                    float* __restrict__ out, int n, int mode,
-                                                                    int edge_arg) {
+__global__ __launch_bounds__(kBlock, DIM == 4 ? 7 : 5) void iou_aligned_compact_kernel(const float* __restrict__ b1,
+                                                                                      const float* __restrict__ b2,
+                                                                                      float* __restrict__ out, int n,
+                                                                                      int mode, int edge_arg) {
     __shared__ WaveQueue<DIM> queues[kBlock / 64];
-    __shared__ int left1[kBlock / 64], left3[kBlock / 64];
+    __shared__ int leftover[kBlock / 64];
     const int edge = ARC ? (int)EDGE_ARC : edge_arg;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     WaveQueue<DIM>& q = queues[wave];
     const int nslices = (n + 63) >> 6;
     const int wave_global = blockIdx.x * (kBlock / 64) + wave, nwaves = gridDim.x * (kBlock / 64);
-    int c1 = 0, c3 = 0;  // wave-uniform stack heights
-    // the general form on one deferred pair per lane
-    auto finish_rare = [&](int j, bool active) {
-        if (active) {
-            float u1[5], u2[5];
-            load_box<DIM>(b1, j, u1);
-            load_box<DIM>(b2, j, u2);
-            out[j] = fast_finish<VARIANT, DIM>(u1, u2, mode, edge);
-        }
-    };
-    // stages 1 + 2 on one S1 record per lane (taken from `src`); rare lanes are pushed on this wave's own S3
-    auto stage12 = [&](const WaveQueue<DIM>& src, int slot, bool active) {
-        bool rare = false;
-        int j = 0;
-        if (active) {
-            float u1[5], u2[5];
-            j = s1_load<DIM>(src, slot, u1, u2);
-            LeanRec rec;
-            const int st = lean_stage1<VARIANT, DIM>(u1, u2, edge, rec);
-            if (st == LEAN_SURVIVOR) out[j] = lean_stage2(rec, mode);
-            else if (st == LEAN_ZERO) out[j] = 0.0f;
-            else rare = true;
-        }
-        const unsigned long long m = __ballot(rare);
-        if (m != 0ull) {   // wave-uniform
-            if (rare) q.rare[c3 + __popcll(m & ((1ull << lane) - 1ull))] = j;
-            c3 += __popcll(m);
-        }
-    };
-    auto drain_rare = [&]() {
-        while (c3 >= 64) {   // wave-uniform
-            c3 -= 64;
-            wave_lds_fence();
-            finish_rare(q.rare[c3 + lane], true);
-        }
-    };
-    // one slice: cull, push the survivors, run stages 1 + 2 when a full wave of records is available
+    int count = 0;  // wave-uniform stack height
+    // one slice: cull, push the survivors, finish 64 of them when a full wave of records is available
     auto slice = [&](const float (&x)[5], const float (&y)[5], int sl) {
         const int i = sl * 64 + lane;
         bool surv = false;
@@ -181,12 +137,14 @@ __global__ __launch_bounds__(kBlock, DIM == 4 ? 6 : 5) void iou_aligned_compact_
             else surv = true;
         }
         const unsigned long long m = __ballot(surv);
-        if (surv) s1_store<DIM>(q, c1 + __popcll(m & ((1ull << lane) - 1ull)), x, y, i);
-        c1 += __popcll(m);
-        if (c1 >= 64) {  // wave-uniform
-            c1 -= 64;
+        if (surv) queue_store<DIM>(q, count + __popcll(m & ((1ull << lane) - 1ull)), x, y, i);
+        count += __popcll(m);
+        if (count >= 64) {  // wave-uniform
+            count -= 64;
             wave_lds_fence();
-            stage12(q, c1 + lane, true);
+            float u1[5], u2[5];
+            const int j = queue_load<DIM>(q, count + lane, u1, u2);
+            out[j] = lean_finish<VARIANT, DIM>(u1, u2, mode, edge);
         }
     };
     auto fetch = [&](int sl, float (&x)[5], float (&y)[5]) {
@@ -194,49 +152,37 @@ __global__ __launch_bounds__(kBlock, DIM == 4 ? 6 : 5) void iou_aligned_compact_
         if (sl < nslices && i < n) { load_box<DIM>(b1, i, x); load_box<DIM>(b2, i, y); }
     };
     if (PREFETCH) {
-        // software prefetch, two register sets used alternately (no copies): while a slice is computed the next one's
-        // boxes are in flight
-        float ax[5] = {0, 0, 0, 0, 0}, ay[5] = {0, 0, 0, 0, 0}, bx[5] = {0, 0, 0, 0, 0}, by[5] = {0, 0, 0, 0, 0};
-        fetch(wave_global, ax, ay);
-        for (int sl = wave_global; sl < nslices; sl += 2 * nwaves) {
-            fetch(sl + nwaves, bx, by);
-            slice(ax, ay, sl);
-            fetch(sl + 2 * nwaves, ax, ay);
-            if (sl + nwaves < nslices) slice(bx, by, sl + nwaves);
-            drain_rare();
+        // software prefetch: the next slice's boxes are in flight while this slice is computed (register double buffer;
+        // two register sets used alternately instead of the copy were measured slower: the loop body doubles)
+        float nx[5] = {0, 0, 0, 0, 0}, ny[5] = {0, 0, 0, 0, 0};
+        fetch(wave_global, nx, ny);
+        for (int sl = wave_global; sl < nslices; sl += nwaves) {
+            float x[5], y[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) { x[k] = nx[k]; y[k] = ny[k]; }
+            fetch(sl + nwaves, nx, ny);
+            slice(x, y, sl);
         }
     } else {
         for (int sl = wave_global; sl < nslices; sl += nwaves) {
             float x[5] = {0, 0, 0, 0, 0}, y[5] = {0, 0, 0, 0, 0};
             fetch(sl, x, y);
             slice(x, y, sl);
-            drain_rare();
         }
     }
-    // merge the < 64 S1 leftovers of the four waves and finish them on as few, as full waves as possible
-    if (lane == 0) left1[wave] = c1;
+    // merge the < 64 leftovers of the four waves and finish them on as few, as full waves as possible
+    if (lane == 0) leftover[wave] = count;
     __syncthreads();
-    {
-        const int a0 = left1[0], a1 = left1[1], a2 = left1[2], a3 = left1[3];
-        const int total = a0 + a1 + a2 + a3;       // <= 252: at most one chunk per wave
-        const int k = wave * 64 + lane;
-        if (wave * 64 < total) {
-            int w, r;
-            locate_leftover(k, a0, a1, a2, w, r);
-            stage12(queues[w], r, k < total);
-        }
-    }
-    // the same for the deferred rare lanes (<= 127 per wave here)
-    if (lane == 0) left3[wave] = c3;
-    __syncthreads();
-    {
-        const int a0 = left3[0], a1 = left3[1], a2 = left3[2], a3 = left3[3];
-        const int total = a0 + a1 + a2 + a3;
-        for (int base = wave * 64; base < total; base += kBlock) {
-            const int k = base + lane;
-            int w = 0, r = 0;
-            if (k < total) locate_leftover(k, a0, a1, a2, w, r);
-            finish_rare(k < total ? queues[w].rare[r] : 0, k < total);
+    const int c0 = leftover[0], c1 = leftover[1], c2 = leftover[2], c3 = leftover[3];
+    const int total = c0 + c1 + c2 + c3;   // <= 252: at most one chunk per wave
+    if (wave * 64 < total) {
+        int k = wave * 64 + lane;
+        if (k < total) {
+            int w = 0;
+            if (k >= c0) { k -= c0; w = 1; if (k >= c1) { k -= c1; w = 2; if (k >= c2) { k -= c2; w = 3; } } }
+            float u1[5], u2[5];
+            const int j = queue_load<DIM>(queues[w], k, u1, u2);
+            out[j] = lean_finish<VARIANT, DIM>(u1, u2, mode, edge);
         }
     }
 }
@@ -244,14 +190,9 @@ __global__ __launch_bounds__(kBlock, DIM == 4 ? 6 : 5) void iou_aligned_compact_
 // ---- pairwise IoU for the assigner call pattern (few rows x many columns), closed-form core ----
 // One thread owns one column box (anchor); a workgroup covers 256 columns x up to 64 rows (GT).  Per-box cull
 // quantities are hoisted: rows live in LDS (broadcast reads), the column's in registers, so a culled pair costs
-// ~15 VALU instructions + one coalesced store of 0.  Cull survivors are (row, column) index pairs on the wave's S1
-// stack; stages 1 + 2 run on 64 of them at a time (row box from LDS, column box re-read through L1/L2); rare lanes are
-// deferred on an index stack S3 exactly as in iou_aligned_compact_kernel and finished per wave at the end.
+// ~15 VALU instructions + one coalesced store of 0.  Survivors are (row, column) index pairs pushed on the wave's
+// LDS stack and finished 64 at a time on fully populated waves (same scheme as iou_aligned_compact_kernel).
 constexpr int kPwRows = 64;
-struct PairQueue {
-    int2 s1[kQCap];
-    int2 s3[kQCap];
-};
 template <int VARIANT, int DIM>
 __global__ __launch_bounds__(kBlock) void iou_pairwise_compact_kernel(const float* __restrict__ b1, int m,
                                                                      const float* __restrict__ b2, int n,
@@ -259,7 +200,7 @@ __global__ __launch_bounds__(kBlock) void iou_pairwise_compact_kernel(const floa
                                                                      int rows_per_wg) {
     __shared__ float row_raw[kPwRows][5];
     __shared__ float4 row_cull[kPwRows];
-    __shared__ PairQueue queues[kBlock / 64];
+    __shared__ int2 stack[kBlock / 64][kQCap];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = blockIdx.y * rows_per_wg, rows = (m - r0 < rows_per_wg) ? m - r0 : rows_per_wg;
     if ((int)threadIdx.x < rows) {
@@ -276,41 +217,14 @@ __global__ __launch_bounds__(kBlock) void iou_pairwise_compact_kernel(const floa
     float a[5] = {0.0f, 0.0f, 1.0f, 1.0f, 0.0f};
     if (valid) load_box<DIM>(b2, j, a);
     const CullBox ca = cull_box(a, edge);
-    PairQueue& q = queues[wave];
-    int c1 = 0, c3 = 0;
-    auto finish_rare = [&](int2 e) {
+    int2* st = stack[wave];
+    int count = 0;
+    auto finish_one = [&](int2 e) {
         float g[5], p[5];
 #pragma unroll
         for (int k = 0; k < 5; k++) g[k] = row_raw[e.x][k];
         load_box<DIM>(b2, e.y, p);
-        out[(int64_t)(r0 + e.x) * n + e.y] = fast_finish<VARIANT, DIM>(g, p, mode, edge);
-    };
-    auto stage12 = [&](int slot, bool active) {
-        bool rare = false;
-        int2 e = make_int2(0, 0);
-        if (active) {
-            e = q.s1[slot];
-            float g[5], p[5];
-#pragma unroll
-            for (int k = 0; k < 5; k++) g[k] = row_raw[e.x][k];
-            load_box<DIM>(b2, e.y, p);
-            LeanRec rec;
-            const int st = lean_stage1<VARIANT, DIM>(g, p, edge, rec);
-            float* dst = out + (int64_t)(r0 + e.x) * n + e.y;
-            if (st == LEAN_SURVIVOR) *dst = lean_stage2(rec, mode);
-            else if (st == LEAN_ZERO) *dst = 0.0f;
-            else rare = true;
-        }
-        const unsigned long long mk = __ballot(rare);
-        if (mk != 0ull) {
-            if (rare) q.s3[c3 + __popcll(mk & ((1ull << lane) - 1ull))] = e;
-            c3 += __popcll(mk);
-            if (c3 >= 64) {
-                c3 -= 64;
-                wave_lds_fence();
-                finish_rare(q.s3[c3 + lane]);
-            }
-        }
+        out[(int64_t)(r0 + e.x) * n + e.y] = lean_finish<VARIANT, DIM>(g, p, mode, edge);
     };
     for (int i = 0; i < rows; i++) {
         const float4 rc = row_cull[i];
@@ -320,18 +234,16 @@ __global__ __launch_bounds__(kBlock) void iou_pairwise_compact_kernel(const floa
             else surv = true;
         }
         const unsigned long long mk = __ballot(surv);
-        if (surv) q.s1[c1 + __popcll(mk & ((1ull << lane) - 1ull))] = make_int2(i, j);
-        c1 += __popcll(mk);
-        if (c1 >= 64) {
-            c1 -= 64;
+        if (surv) st[count + __popcll(mk & ((1ull << lane) - 1ull))] = make_int2(i, j);
+        count += __popcll(mk);
+        if (count >= 64) {
+            count -= 64;
             wave_lds_fence();
-            stage12(c1 + lane, true);
+            finish_one(st[count + lane]);
         }
     }
     wave_lds_fence();
-    if (c1 > 0) stage12(lane, lane < c1);
-    wave_lds_fence();
-    if (lane < c3) finish_rare(q.s3[lane]);
+    if (lane < count) finish_one(st[lane]);
 }
 
 // out[i*n + j]: consecutive lanes walk j (coalesced stores, b2 loads coalesced, b1 row is a broadcast).
@@ -788,8 +700,8 @@ struct AlignedLaunch {
             // rather than full survivor stacks.  Hence: whole multiples of the CU count, at most 6 per CU (and never
             // more than the LDS admits), at least one 64-pair slice per wave.
             const int64_t kCUs = cu_count();
-            int64_t resident = (160 * 1024) / pipe_lds_bytes(D);
-            if (resident > (D == 4 ? 6 : 5)) resident = D == 4 ? 6 : 5;   // the kernel's __launch_bounds__ (registers)
+            int64_t resident = (160 * 1024) / queue_lds_bytes(D);
+            if (resident > (D == 4 ? 6 : 5)) resident = D == 4 ? 6 : 5;   // registers (__launch_bounds__) would admit 7 / 5
             int64_t slices = (n + 63) / 64;
             int64_t wgs = (slices + 3) / 4;
             if (g_slices_per_wave > 0) wgs = (slices + 4 * g_slices_per_wave - 1) / (4 * g_slices_per_wave);

@@ -111,19 +111,3 @@ int harness_planar_iou(const float* p1, const float* p2, int64_t n, int mode, fl
 }
 }
 
-// stage classification of the lean pipeline per pair: 0 culled (stage 0), 1 separated (stage 1), 2 rare, 3 clip survivor
-template <int V, int DIM>
-static void stage_loop(const float* b1, const float* b2, int64_t n, int* out) {
-    for (int64_t i = 0; i < n; i++) {
-        float x[5] = {0, 0, 0, 0, 0}, y[5] = {0, 0, 0, 0, 0};
-        for (int k = 0; k < DIM; k++) { x[k] = b1[i * DIM + k]; y[k] = b2[i * DIM + k]; }
-        if (fast_cull<DIM>(x, y, EDGE_ARC)) { out[i] = 0; continue; }
-        LeanRec r;
-        const int st = lean_stage1<V, DIM>(x, y, EDGE_ARC, r);
-        out[i] = st == LEAN_ZERO ? 1 : st == LEAN_RARE ? 2 : 3;
-    }
-}
-extern "C" void harness_lean_stage(const float* b1, const float* b2, int64_t n, int dim, int variant, int* out) {
-    if (dim == 4) { if (variant == 0) stage_loop<0, 4>(b1, b2, n, out); else stage_loop<1, 4>(b1, b2, n, out); }
-    else { if (variant == 0) stage_loop<0, 5>(b1, b2, n, out); else stage_loop<1, 5>(b1, b2, n, out); }
-}
