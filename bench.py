@@ -1,50 +1,123 @@
 #!/usr/bin/env python3
 """bench.py — Sph2Pob spherical-IoU throughput on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch of synthetic boxes resident in HBM:
-aligned `sph2pob_standard_iou` over 1,000,000 BFoV pairs per GPU (BASELINE.json configs[1]); for N > 1 every
-rank owns its own 1 M-pair shard (N = 8: the 8 M pairs of configs[4] sharded 8x).  Box pairs are independent, so the
-path shards with NO data-path collective: results stay on the rank that owns the shard (their consumers — assigner,
-loss, NMS — are sharded the same way).  `--gather` additionally assembles the per-shard IoU vectors on every rank with
-one RCCL all_gather_into_tensor per step, double-buffered so that the collective of step i (RCCL's stream) overlaps
-the kernel of step i+1 (4 MB per rank per step: wire + launch time of the collective exceeds the 10 us kernel, so that
-variant is communication-bound by construction).
-`value` = pairs processed by all ranks / max-over-ranks wall time.  Weak scaling (per-GPU work fixed).
-Timing: W warm-up steps (topped up to 3 000 untimed steps — the clocks only settle after a few thousand back-to-back
-launches; the count is reported as config.untimed_steps_before_timing), barrier + synchronize, exactly K timed steps,
-barrier + synchronize, max over ranks.
+N = 1 runs in this process.  N > 1 starts its own ranks: when WORLD_SIZE is not in the environment the parent — before
+it imports torch or touches a GPU — starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 ... bench.py <same arguments>` as a child process and relays rank 0's JSON line and the exit code;
+launched by torch.distributed.run directly (WORLD_SIZE set) it is one of the ranks.
+
+One "step" = one pass of the hot path over one batch of synthetic boxes resident in HBM: aligned
+`sph2pob_standard_iou` (closed-form arithmetic, the default) over the batch.
+  N = 1   1,000,000 BFoV pairs (BASELINE.json configs[1]).
+  N > 1   strong scaling of configs[4]: 8,000,000 BFoV pairs in total, rank r owns the contiguous slice
+          [r T/N, (r+1) T/N) (generated on the rank: scattering 36 B/pair over xGMI would cost more than computing),
+          and the step INCLUDES the north-star exchange: one RCCL `all_gather_into_tensor` of the per-shard IoU vectors
+          per step, double-buffered so that the collective of step i (RCCL's stream) overlaps the kernel of step i+1.
+          Box pairs are independent, so computing needs no collective; the consumers (assigner, loss, NMS) shard the
+          same way.  The same job therefore also times the step WITHOUT the gather (`no_gather`) and, on rank 0, the
+          whole batch on one GPU (`strong_scaling.one_gpu_ms`), so that the line carries the speed-ups by itself.
+  `--scaling weak --pairs P` keeps P pairs per GPU instead; `--total-pairs T` changes the batch.
+`value` = pairs processed by all ranks / max-over-ranks wall time of the K timed steps.
+Timing: W warm-up steps as asked, topped up to 3 000 untimed steps (the clocks only settle after a few thousand
+back-to-back launches; reported as config.untimed_steps_before_timing, and the figure measured with exactly W warm-up
+steps is reported next to it as `unsettled`), barrier + synchronize, exactly K timed steps, barrier + synchronize, max
+over ranks.
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel (iou_aligned) against the HBM roofline: algorithmic bytes = 36 B/pair
-                (2 x 16 B boxes in + 4 B IoU out) / average launch duration measured here with
-                HIP events on the launch stream; `traffic` = PMC-measured HBM bytes per launch when
-                profiles/ holds a summary for this round (collected in separate rocprofv3 --pmc passes), else null.
-  cpu_baseline  the CPU oracle (C restatement of the reference path, "port") timed on this host's cores on a
-                bounded sample of the same workload.
+  roofline      the dominant kernel (iou_aligned_compact_kernel) against the HBM roofline: algorithmic bytes = 36 B/pair
+                (2 x 16 B boxes in + 4 B IoU out) / average launch duration measured here with HIP events
+                on the launch stream.  `traffic` (PMC-measured HBM bytes per launch) and `valu_active_frac` come from
+                this round's committed rocprofv3 summary (separate --pmc passes) and are only attached when this run's
+                configuration matches the one profiled; `cold` repeats the measurement rotating through 10 distinct
+                input / output sets (360 MB > the 256 MiB Infinity Cache: every launch streams from HBM), `at_8m` is one
+                8 M-pair launch (288 MB).
+  cpu_baseline  the CPU oracle (C restatement of the reference path, "port") timed on this host's cores on a bounded
+                sample of the same workload, next to the reference's own Python timings.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PAIRS_PER_GPU = 1_000_000
+PAIRS_ONE_GPU = 1_000_000    # configs[1]
+PAIRS_SHARDED = 8_000_000    # configs[4]
 BYTES_PER_PAIR = 36          # aligned BFoV: 2 * 16 B read + 4 B written
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 VARIANT = 'standard'
-
-
 CLOCK_SETTLE_STEPS = 3000
+COLD_SETS = 10               # x 36 MB per 1 M pairs = 360 MB > 256 MiB Infinity Cache
 
 
-def rank_env():
-    return int(os.environ.get('RANK', '0'))
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5000)
+    ap.add_argument('--warmup', type=int, default=500)
+    ap.add_argument('--scaling', default='strong', choices=['strong', 'weak'],
+                    help='N > 1: strong = --total-pairs split N ways (default); weak = --pairs per GPU')
+    ap.add_argument('--total-pairs', type=int, default=None, help='strong scaling: pairs per step over all ranks '
+                    f'(default {PAIRS_ONE_GPU:,} for one GPU, {PAIRS_SHARDED:,} for several)')
+    ap.add_argument('--pairs', type=int, default=None, help='pairs per GPU per step (weak scaling; one GPU: the batch)')
+    ap.add_argument('--variant', default=VARIANT, choices=['standard', 'efficient', 'legacy'])
+    ap.add_argument('--arithmetic', default='fast', choices=['fast', 'robust', 'reference'],
+                    help="'fast' = default closed-form core ('robust' is an alias of it since round 2); 'reference' = the "
+                         "reference's fp32 operation order")
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--gather', dest='gather', action='store_true', default=None,
+                    help='N > 1: one RCCL all-gather of the per-shard IoU vectors per step, pipelined one step deep (default)')
+    ap.add_argument('--no-gather', dest='gather', action='store_false', help='N > 1: time the sharded step only')
+    ap.add_argument('--no-extras', action='store_true', help='skip the cold-HBM / 8 M-pair / unsettled side measurements')
+    ap.add_argument('--force-dist', action='store_true', help='initialise the process group even with one rank (tests)')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='CPU rehearsal of the launch / shard / gather logic on gloo with a stand-in operator (no kernel, '
+                         'no roofline): what the CPU test-suite drives')
+    return ap.parse_args(argv)
+
+
+def shard_plan(args, world):
+    """(pairs per rank as a list, total, label)."""
+    from sph_retina_amd.parallel import shard_bounds
+    if world > 1 and args.scaling == 'weak':
+        per = args.pairs or PAIRS_ONE_GPU
+        return [per] * world, per * world, 'weak'
+    total = args.total_pairs or (args.pairs if world == 1 and args.pairs else (PAIRS_ONE_GPU if world == 1 else PAIRS_SHARDED))
+    counts = [hi - lo for lo, hi in (shard_bounds(total, world, r) for r in range(world))]
+    return counts, total, 'strong'
+
+
+def self_launch(args, argv):
+    """Parent of an N > 1 run: start the ranks as a child process tree and relay rank 0's line.  Nothing here touches a
+    GPU (a GPU-initialised process must not fork + exec on this pool), and the native libraries are built first so the
+    ranks do not race on them."""
+    from sph_retina_amd import _lib
+    if not args.dry_run:
+        _lib.build()
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{')]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith('{'):
+            print(ln, file=sys.stderr)
+    if proc.returncode == 0 and len(lines) != 1:
+        print(f'bench.py: expected one JSON line from rank 0, got {len(lines)}', file=sys.stderr)
+        return 1
+    for ln in lines:
+        print(ln)
+    return proc.returncode
 
 
 def make_boxes(n, seed, device):
@@ -59,7 +132,6 @@ def make_boxes(n, seed, device):
 
 def cpu_baseline(n_sample=1_000_000):
     """Oracle timed on the host: the checker used as a reported baseline, never as the thing shipped."""
-    import numpy as np
     from oracle import oracle as O
     O.build()
     b1 = O.generate_boxes(n_sample, 0)
@@ -77,89 +149,110 @@ def cpu_baseline(n_sample=1_000_000):
     single = 200000 / (time.perf_counter() - t1)
     return {'value': reps * n_sample / t_total, 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
             'sample': f'{reps} x {n_sample} uniform BFoV pairs, sph2pob_{VARIANT}_iou, C oracle (OpenMP)',
-            'single_core_pairs_per_s': single}
+            'single_core_pairs_per_s': single,
+            # the reference's own Python on the same workload cannot run on the GPU box (it never travels); its timings
+            # from the build container are quoted beside the port so that "the reference's CPU path" is in one place
+            'reference_python': {'value': 1e6 / (0.184 + 2.24), 'unit': 'pairs/s', 'cores': 8,
+                                 'sample': '1 x 1,000,000 uniform BFoV pairs: sph2pob_standard 0.184 s + vendored planar '
+                                           'rotated IoU 2.24 s, torch CPU, 8 threads',
+                                 'source': 'BASELINE.md §3 (measured in the build container, not on this host)'}}
 
 
-def pmc_traffic():
-    """HBM bytes per launch from the committed PMC summary of this round (profiles/pmc_summary.json)."""
+def pmc_summary(pairs, variant, arithmetic, kernel):
+    """This round's committed PMC summary (profiles/pmc_summary.json), ONLY when it was collected for this very
+    configuration: a figure measured for another batch size / variant / build is not this run's measurement."""
     path = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
     try:
         with open(path) as f:
-            return json.load(f).get('iou_aligned', {}).get('hbm_bytes_per_launch')
+            d = json.load(f).get('iou_aligned', {})
     except (OSError, ValueError):
-        return None
+        return {}
+    cfg = d.get('config', {})
+    if (cfg.get('pairs'), cfg.get('variant'), cfg.get('arithmetic')) != (pairs, variant, arithmetic) or \
+            kernel not in d.get('kernel', ''):
+        return {}
+    return d
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5000)
-    ap.add_argument('--warmup', type=int, default=500)
-    ap.add_argument('--pairs', type=int, default=PAIRS_PER_GPU, help='pairs per GPU per step')
-    ap.add_argument('--variant', default=VARIANT, choices=['standard', 'efficient', 'legacy'])
-    ap.add_argument('--arithmetic', default='fast', choices=['fast', 'robust', 'reference'],
-                    help="'fast' = default closed-form core; 'reference' = the reference's fp32 operation order")
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--gather', action='store_true',
-                    help='N > 1: also assemble the per-shard IoU vectors on every rank with one RCCL all-gather per step '
-                         '(pipelined one step deep); default: shards stay on their ranks, no data-path collective')
-    ap.add_argument('--force-dist', action='store_true', help='initialise the process group even with one rank (tests)')
-    args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    from sph_retina_amd import _lib, _torch_glue as G
-    if rank_env() == 0:
-        _lib.build()   # no-op when sph_retina_amd/lib/libsph2pob_hip.so is up to date
-        if not args.no_cpu_baseline:
-            # the CPU-baseline leg's checker is built here, BEFORE this process initialises the GPU: on this pool a
-            # process must not fork + exec (make / gcc) once it has touched the device
-            from oracle import oracle as _O
-            _O.build()
-    else:
-        for _ in range(600):   # other ranks wait for rank 0's build instead of racing it
-            if not _lib._stale():
-                break
-            time.sleep(0.5)
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args, argv))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+
+    import torch
+    import torch.distributed as dist
+    from sph_retina_amd import _lib, _torch_glue as G
+    dry = args.dry_run
+    if not dry:
+        if rank == 0:
+            _lib.build()   # no-op when sph_retina_amd/lib/libsph2pob_hip.so is up to date
+            if not args.no_cpu_baseline and world == 1:
+                # the CPU-baseline leg's checker is built here, BEFORE this process initialises the GPU: on this pool a
+                # process must not fork + exec (make / gcc) once it has touched the device
+                from oracle import oracle as _O
+                _O.build()
+        else:
+            for _ in range(600):   # other ranks wait for rank 0's build instead of racing it
+                if not _lib._stale():
+                    break
+                time.sleep(0.5)
+
     use_dist = world > 1 or args.force_dist
+    if dry:
+        dev = torch.device('cpu')
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
     if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-    gather = use_dist and args.gather
+        if dry:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+    counts, total, scaling = shard_plan(args, world)
+    n = counts[rank]
+    equal = len(set(counts)) == 1
+    gather = (world > 1) if args.gather is None else (args.gather and use_dist)
+    if gather and not equal:
+        raise SystemExit('--gather needs equal shards (total pairs divisible by the number of GPUs)')
 
-    n = args.pairs
     b1 = make_boxes(n, 2 * rank, dev)        # rank r owns its own contiguous shard, generated per rank
     b2 = make_boxes(n, 2 * rank + 1, dev)
-    # this rank's IoU vector and the assembled vector, double-buffered so that the RCCL all-gather of step i (on the
+    # this rank's IoU vector and the assembled vector, double-buffered so that the all-gather of step i (on the
     # process group's own stream) overlaps the kernel of step i+1 (pre-allocated, SURVEY §8d)
-    shards = [torch.empty(n, dtype=torch.float32, device=dev) for _ in range(2 if gather else 1)]
+    shards = [torch.empty(n, dtype=torch.float32, device=dev) for _ in range(2)]
     gathered = [torch.empty(world * n, dtype=torch.float32, device=dev) for _ in range(2)] if gather else None
-    shard = shards[0]
     pending = [None, None]
-    lib = _lib.lib()
-    stream = torch.cuda.current_stream(dev)
-    G.set_arithmetic(args.arithmetic)
-    variant_c = G.VARIANTS[args.variant]
+    if dry:
+        def kernel(x1, x2, out, m, stream=None):   # stand-in operator: the rehearsal is about launch / shard / gather
+            torch.sub(x1[:, 0], x2[:, 0], out=out)
+    else:
+        lib = _lib.lib()
+        stream = torch.cuda.current_stream(dev)
+        G.set_arithmetic(args.arithmetic)
+        variant_c = G.VARIANTS[args.variant]
 
-    def step(i):
-        k = i & 1 if gather else 0
-        if gather and pending[k] is not None:
+        def kernel(x1, x2, out, m, stream=stream):
+            rc = lib.sph2pob_iou_aligned_f32(G.ptr(x1), G.ptr(x2), G.ptr(out), ctypes.c_int64(m), 4, variant_c, 0, 0, 0,
+                                             ctypes.c_void_p(stream.cuda_stream))
+            if rc:
+                _lib.check(rc, 'sph2pob_iou_aligned_f32')
+
+    def step(i, with_gather):
+        k = i & 1
+        if with_gather and pending[k] is not None:
             pending[k].wait()          # stream-ordered: the kernel below waits for the collective that read shards[k]
-        rc = lib.sph2pob_iou_aligned_f32(G.ptr(b1), G.ptr(b2), G.ptr(shards[k]), ctypes.c_int64(n), 4, variant_c, 0, 0, 0,
-                                         ctypes.c_void_p(stream.cuda_stream))
-        if rc:
-            _lib.check(rc, 'sph2pob_iou_aligned_f32')
-        if gather:
+        kernel(b1, b2, shards[k], n)
+        if with_gather:
             pending[k] = dist.all_gather_into_tensor(gathered[k], shards[k], async_op=True)
 
     def drain():
@@ -172,64 +265,136 @@ def main():
         drain()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if not dry:
+            torch.cuda.synchronize(dev)
 
-    # W warm-up steps as asked, topped up to CLOCK_SETTLE_STEPS untimed steps: the GPU clocks only settle after a few
-    # thousand back-to-back launches (20 launches in a row run at 10.9 us each, 5 000 at 9.3 us), whatever W is
-    for i in range(max(args.warmup, CLOCK_SETTLE_STEPS)):
-        step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(steps, with_gather):
+        """K steps bracketed by barrier + synchronize on both sides; max over ranks."""
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i, with_gather)
+        barrier()
+        el = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
 
-    # dominant-kernel duration: HIP events on the launch stream around K back-to-back launches (no collective)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    k_launch = max(args.steps, 1000)   # long enough for a stable average whatever K is
-    torch.cuda.synchronize(dev)
-    ev0.record(stream)
-    for _ in range(k_launch):
-        lib.sph2pob_iou_aligned_f32(G.ptr(b1), G.ptr(b2), G.ptr(shard), ctypes.c_int64(n), 4, variant_c, 0, 0, 0,
-                                    ctypes.c_void_p(stream.cuda_stream))
-    ev1.record(stream)
-    torch.cuda.synchronize(dev)
-    kernel_ms = ev0.elapsed_time(ev1) / k_launch
-    checksum = float(shard.double().sum().item())
+    settle = 0 if dry else CLOCK_SETTLE_STEPS
+    extras = not args.no_extras and not dry
+    unsettled = None
+    for i in range(args.warmup):
+        step(i, gather)
+    if extras:
+        # what the literal contract measures: exactly W warm-up steps, then K steps (the clocks are still ramping)
+        el = timed(args.steps, gather)
+        unsettled = {'ms_per_step': el / args.steps * 1e3, 'value': total * args.steps / el, 'untimed_steps_before_timing': args.warmup}
+    for i in range(max(settle - args.warmup - (args.steps if extras else 0), 0)):
+        step(i, gather)
+    elapsed = timed(args.steps, gather)
+    no_gather = None
+    if gather:
+        el = timed(args.steps, False)
+        no_gather = {'ms_per_step': el / args.steps * 1e3, 'value': total * args.steps / el}
+    checksum = float(shards[0].double().sum().item())
+
+    # ---- side measurements on rank 0 (the other ranks wait at the final barrier) ----
+    kernel_ms = cold = at_8m = one_gpu_ms = None
+    if not dry:
+        def events_ms(fn, reps):
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            ev0.record(stream)
+            for r in range(reps):
+                fn(r)
+            ev1.record(stream)
+            torch.cuda.synchronize(dev)
+            return ev0.elapsed_time(ev1) / reps
+        # dominant-kernel duration: HIP events on the launch stream around back-to-back launches (no collective)
+        kernel_ms = events_ms(lambda r: kernel(b1, b2, shards[0], n), max(args.steps, 1000))
+        if rank == 0 and extras:
+            m1 = PAIRS_ONE_GPU
+            sets = [(make_boxes(m1, 100 + 2 * k, dev), make_boxes(m1, 101 + 2 * k, dev),
+                     torch.empty(m1, dtype=torch.float32, device=dev)) for k in range(COLD_SETS)]
+            events_ms(lambda r: kernel(*sets[r % COLD_SETS], m1), 500)
+            t = events_ms(lambda r: kernel(*sets[r % COLD_SETS], m1), 2000)
+            gbs = BYTES_PER_PAIR * m1 / (t * 1e-3) / 1e9
+            cold = {'pairs': m1, 'distinct_sets': COLD_SETS, 'working_set_bytes': COLD_SETS * BYTES_PER_PAIR * m1,
+                    'kernel_ms': t, 'achieved': gbs, 'frac': gbs / HBM_PEAK_GBS}
+            del sets
+            m8 = PAIRS_SHARDED
+            c1, c2, co = make_boxes(m8, 200, dev), make_boxes(m8, 201, dev), torch.empty(m8, dtype=torch.float32, device=dev)
+            events_ms(lambda r: kernel(c1, c2, co, m8), 100)
+            t = events_ms(lambda r: kernel(c1, c2, co, m8), 300)
+            gbs = BYTES_PER_PAIR * m8 / (t * 1e-3) / 1e9
+            at_8m = {'pairs': m8, 'kernel_ms': t, 'achieved': gbs, 'frac': gbs / HBM_PEAK_GBS}
+            if world > 1 and total == m8:
+                one_gpu_ms = t
+            del c1, c2, co
+        if rank == 0 and world > 1 and one_gpu_ms is None and scaling == 'strong':
+            c1, c2, co = make_boxes(total, 200, dev), make_boxes(total, 201, dev), torch.empty(total, dtype=torch.float32, device=dev)
+            events_ms(lambda r: kernel(c1, c2, co, total), 100)
+            one_gpu_ms = events_ms(lambda r: kernel(c1, c2, co, total), 300)
+            del c1, c2, co
 
     if rank == 0:
-        achieved = BYTES_PER_PAIR * n / (kernel_ms * 1e-3) / 1e9
+        ms = elapsed / args.steps * 1e3
+        kern = 'iou_aligned_compact_kernel' if args.arithmetic != 'reference' and args.variant != 'legacy' else 'iou_aligned_kernel'
         out = {
-            'metric': 'box-pairs/sec, Sph2Pob spherical IoU (aligned BFoV, fp32), 1M pairs per MI355X',
-            'value': world * n * args.steps / elapsed,
+            'metric': 'box-pairs/sec, Sph2Pob spherical IoU (aligned BFoV, fp32), '
+                      + (f'{total:,} pairs per launch on one MI355X' if world == 1 else
+                         f'{total:,} pairs per step over {world} MI355X'
+                         + (' incl. the RCCL all-gather of the shards' if gather else ''))
+                      + ('' if dry else f' (clock-settled: {max(settle, args.warmup)} untimed steps before timing)'),
+            'value': total * args.steps / elapsed,
             'unit': 'pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3,
+            'ms_per_step': ms,
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': scaling,
             'vs_baseline': None,   # BASELINE.json:published is empty (README T_cuda has no stated hardware)
             'dtype': 'f32',
-            'data': 'synthetic',
-            'config': {'workload': f'{n:,} uniform random BFoV pairs per GPU, sph2pob_{args.variant}_iou aligned '
-                                   f'(BASELINE configs[1]{"; x%d shards" % world if world > 1 else ""}{" + RCCL all-gather of the shards, pipelined one step deep" if gather else ""})',
-                       'pairs_per_gpu': n, 'variant': args.variant, 'arithmetic': args.arithmetic, 'parallelism': f'shard{world}', 'gather': bool(gather),
-                       'untimed_steps_before_timing': max(args.warmup, CLOCK_SETTLE_STEPS)},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(),
-                         'kernel': 'iou_aligned_compact_kernel' if args.arithmetic == 'fast' and args.variant != 'legacy'
-                         else 'iou_aligned_kernel', 'kernel_ms': kernel_ms,
-                         'algorithmic_bytes_per_launch': BYTES_PER_PAIR * n},
-            'readme_t_cuda_ratio': (n / (kernel_ms * 1e-3)) / (1e6 / 0.0096),
+            'data': 'synthetic' if not dry else 'dry-run (gloo, stand-in operator, no kernel)',
+            'config': {'workload': (f'{total:,} uniform random BFoV pairs per step, sph2pob_{args.variant}_iou aligned: '
+                                    + ('BASELINE configs[1] on one GPU' if world == 1 and total == PAIRS_ONE_GPU else
+                                       'BASELINE configs[4]' if total == PAIRS_SHARDED else 'custom batch')
+                                    + (f', contiguous shards of {counts[0]:,} pairs on {world} GPUs' if world > 1 else '')
+                                    + (', one RCCL all-gather of the shards per step, pipelined one step deep' if gather else '')),
+                       'total_pairs': total, 'pairs_per_gpu': counts[0], 'variant': args.variant, 'arithmetic': args.arithmetic,
+                       'parallelism': f'shard{world}', 'gather': bool(gather),
+                       'untimed_steps_before_timing': max(settle, args.warmup)},
             'checksum': checksum,
         }
-        if not args.no_cpu_baseline:
+        if not dry:
+            achieved = BYTES_PER_PAIR * n / (kernel_ms * 1e-3) / 1e9
+            pmc = pmc_summary(n, args.variant, 'fast' if args.arithmetic == 'robust' else args.arithmetic, kern)
+            out['roofline'] = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                               'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc.get('hbm_bytes_per_launch'),
+                               'traffic_source': pmc.get('source') if pmc.get('hbm_bytes_per_launch') else None,
+                               'valu_active_frac': pmc.get('valu_active_frac'),
+                               'kernel': kern, 'kernel_ms': kernel_ms, 'pairs_per_launch': n,
+                               'algorithmic_bytes_per_launch': BYTES_PER_PAIR * n}
+            if cold:
+                out['roofline']['cold'] = cold
+            if at_8m:
+                out['roofline']['at_8m'] = at_8m
+            out['readme_t_cuda_ratio'] = (n / (kernel_ms * 1e-3)) / (1e6 / 0.0096)
+        if unsettled:
+            out['unsettled'] = unsettled
+        if no_gather:
+            out['no_gather'] = no_gather
+        if world > 1 and scaling == 'strong':
+            ss = {'total_pairs': total, 'one_gpu_ms': one_gpu_ms}
+            if one_gpu_ms:
+                ss['speedup'] = one_gpu_ms / ms
+                if no_gather:
+                    ss['speedup_no_gather'] = one_gpu_ms / no_gather['ms_per_step']
+            out['strong_scaling'] = ss
+        if not args.no_cpu_baseline and not dry and world == 1:   # rank 0 at N = 1 only
             out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -141,9 +141,11 @@ constexpr float kMinAng = 4.8828125e-4f;     // acos(float(1 - 1e-7))
 constexpr float kCosMinAng = 0.99999988f;    // cos(kMinAng) in fp32 = the clamp bound itself
 
 // rotate (c, s) by +ang where (ca, sa) = (cos ang, sin ang)
+// (explicit FMAs, contraction off: lean_finish is inlined several times per kernel — in-loop and tail copies, aligned /
+// pairwise / NMS kernels — and a pair must get the same bits whichever copy finishes it; left to the compiler, the
+// choice of which product of a*b + c*d is fused differs between copies)
 SPH_DEV void rot(float& c, float& s, float ca, float sa) {
-#pragma clang fp contract(fast)
-    float c2 = c * ca - s * sa, s2 = s * ca + c * sa;
+    const float c2 = fmaf(c, ca, -(s * sa)), s2 = fmaf(s, ca, c * sa);
     c = c2;
     s = s2;
 }
@@ -173,21 +175,21 @@ SPH_DEV float clip_len3(float mx, float my, float rx, float ry, float len) {
 // differences that decide near-parallel, near-coincident edges (identical boxes after the jitter).
 SPH_DEV float edges_inside3(float px, float py, float c, float s, float ic, float is, float aic, float ais, float hw,
                             float hh, float hwy, float hhy, float w, float h, bool with_origin_terms) {
-#pragma clang fp contract(fast)
-    float ux = hw * c, uy = hw * s, vx = -hh * s, vy = hh * c;
-    float k0x = (px + ux) + vx, k0y = (py + uy) + vy;
-    float k1x = (px - ux) + vx, k1y = (py - uy) + vy;
-    float k2x = 2.0f * px - k0x, k2y = 2.0f * py - k0y;
-    float k3x = 2.0f * px - k1x, k3y = 2.0f * py - k1y;
-    float rux = hwy * aic, ruy = hhy * ais, rvx = hwy * ais, rvy = hhy * aic;
+    // explicit FMAs, contraction off (see rot)
+    const float ux = hw * c, uy = hw * s, vx = -hh * s, vy = hh * c;
+    const float k0x = (px + ux) + vx, k0y = (py + uy) + vy;
+    const float k1x = (px - ux) + vx, k1y = (py - uy) + vy;
+    const float k2x = fmaf(2.0f, px, -k0x), k2y = fmaf(2.0f, py, -k0y);
+    const float k3x = fmaf(2.0f, px, -k1x), k3y = fmaf(2.0f, py, -k1y);
+    const float rux = hwy * aic, ruy = hhy * ais, rvx = hwy * ais, rvy = hhy * aic;
     // e0: k0, dir -u^ = (-c, -s); e1: k1, dir -v^ = (s, -c); e2: k2, dir +u^; e3: k3, dir +v^ = (-s, c)
-    float l0 = clip_len3(k0x * ic, k0y * is, rux, ruy, w);
-    float l1 = clip_len3(-k1x * is, k1y * ic, rvx, rvy, h);
-    float l2 = clip_len3(-k2x * ic, -k2y * is, rux, ruy, w);
-    float l3 = clip_len3(k3x * is, -k3y * ic, rvx, rvy, h);
-    if (!with_origin_terms) return hh * (l0 + l2) + hw * (l1 + l3);
-    float xu = px * s - py * c, xv = px * c + py * s;
-    return (l0 * (hh - xu) + l2 * (hh + xu)) + (l1 * (hw - xv) + l3 * (hw + xv));
+    const float l0 = clip_len3(k0x * ic, k0y * is, rux, ruy, w);
+    const float l1 = clip_len3(-k1x * is, k1y * ic, rvx, rvy, h);
+    const float l2 = clip_len3(-k2x * ic, -k2y * is, rux, ruy, w);
+    const float l3 = clip_len3(k3x * is, -k3y * ic, rvx, rvy, h);
+    if (!with_origin_terms) return fmaf(hh, l0 + l2, hw * (l1 + l3));
+    const float xu = fmaf(px, s, -(py * c)), xv = fmaf(px, c, py * s);
+    return fmaf(l0, hh - xu, l2 * (hh + xu)) + fmaf(l1, hw - xv, l3 * (hw + xv));
 }
 
 // Intersection area of two NEARLY PARALLEL (or nearly perpendicular) rectangles, fp32, first order in the small
@@ -472,7 +474,7 @@ SPH_DEV void fast_planar(const FastRec& r, PlanarPair& o) {
 // A NaN coordinate gives NaN, as the reference's torch.clamp chain does (sph_iou_api.py:86, :244-260).
 template <int VARIANT, int DIM>
 SPH_DEV float lean_finish(const float (&in1)[5], const float (&in2)[5], int mode, int edge) {
-#pragma clang fp contract(fast)
+    // explicit FMAs, contraction off (see rot): the same bits from every inlined copy
     const float e = (float)kEpsS, e2 = (float)(2 * kEpsS), ea = (float)kEpsA;
     const bool bad = pair_has_nan<DIM>(in1, in2);
     // ---- jitter_spherical (sph_iou_api.py:244-260): shift only where `similar`, clamps always ----
@@ -503,12 +505,13 @@ SPH_DEV float lean_finish(const float (&in1)[5], const float (&in2)[5], int mode
     sincos_colat(phg, sg, cg);
     sincos_colat(php, sp, cp);
     sin_vers_double(0.5f * (thp - thg), sD, h2);
-    const float q = sp * cg - cp * sg;
-    const float N = q - sp * cg * h2, D = -sp * sD;
-    const float Np = q + sg * cp * h2, Dp = -sg * sD;
-    const float C = (cg * cp + sg * sp) - sg * sp * h2;
+    const float spcg = sp * cg, sgcp = sg * cp, sgsp = sg * sp;
+    const float q = spcg - sgcp;                     // sin(phi_p - phi_g)
+    const float N = fmaf(-spcg, h2, q), D = -sp * sD;
+    const float Np = fmaf(sgcp, h2, q), Dp = -sg * sD;
+    const float C = fmaf(-sgsp, h2, fmaf(cg, cp, sgsp));
     // ---- planar boxes as (cos, sin) (fast_planar) ----
-    const float S2 = N * N + D * D;
+    const float S2 = fmaf(N, N, D * D);
     const float iS = fast_rsq(S2);
     float A = atan2_r(S2 * iS, C);
     A = fmaxf(A, VARIANT == VARIANT_STANDARD ? 2.0f * kMinAng : kMinAng);
@@ -536,7 +539,7 @@ SPH_DEV float lean_finish(const float (&in1)[5], const float (&in2)[5], int mode
     }
     // ---- rotated jitter (sph_iou_api.py:222-242) on (x, w, h, a); its decisions need real angles only when the two
     // angles are within ~1.8e-3 of each other modulo 2 pi ----
-    float c = ca * cb + sa * sb, s = sa * cb - ca * sb;  // cos / sin of (a_g - a_p)
+    float c = fmaf(ca, cb, sa * sb), s = fmaf(sa, cb, -(ca * sb));  // cos / sin of (a_g - a_p)
     bool sim = (A < e) | (fabsf(wg - wp) < e) | (fabsf(hg - hp) < e);
     bool close = false;
     const bool cand = (c > 0.5f) & (fabsf(s) < 2.0e-3f);
@@ -571,8 +574,10 @@ SPH_DEV float lean_finish(const float (&in1)[5], const float (&in2)[5], int mode
             rot(ca, sa, (float)0.99999923792122, (float)1.2345674864e-3);  // cos/sin(ea)
             rot(cb, sb, (float)0.99999695168547, (float)2.4691330913e-3);  // cos/sin(2ea)
         }
-        c = ca * cb + sa * sb;
-        s = sa * cb - ca * sb;
+        if (sim | close) {   // only the lanes whose angles moved: the others keep their bits whatever the wave holds
+            c = fmaf(ca, cb, sa * sb);
+            s = fmaf(sa, cb, -(ca * sb));
+        }
     }
     wg = fmaxf(wg, (float)(2 * kEpsA / 10)); hg = fmaxf(hg, (float)(2 * kEpsA / 10));
     wp = fmaxf(wp, (float)(kEpsA / 10));     hp = fmaxf(hp, (float)(kEpsA / 10));
@@ -592,8 +597,8 @@ SPH_DEV float lean_finish(const float (&in1)[5], const float (&in2)[5], int mode
                 if (k1 != a1 || k2 != a2) {
                     sincos_r(k1 - twopi * rintf(k1 / twopi), sa, ca);
                     sincos_r(k2 - twopi * rintf(k2 / twopi), sb, cb);
-                    c = ca * cb + sa * sb;
-                    s = sa * cb - ca * sb;
+                    c = fmaf(ca, cb, sa * sb);
+                    s = fmaf(sa, cb, -(ca * sb));
                 }
             }
         }
@@ -603,8 +608,8 @@ SPH_DEV float lean_finish(const float (&in1)[5], const float (&in2)[5], int mode
     const float ic = fminf(fmaxf(fast_rcp(c), -kBig), kBig), is = fminf(fmaxf(fast_rcp(s), -kBig), kBig);
     const float aic = fabsf(ic), ais = fabsf(is);
     const float hwa = 0.5f * wg, hha = 0.5f * hg, hwb = 0.5f * wp, hhb = 0.5f * hp;
-    const float pax = -(dx * cb + dy * sb), pay = -(dy * cb - dx * sb);
-    const float pbx = dx * ca + dy * sa, pby = dy * ca - dx * sa;
+    const float pax = -fmaf(dx, cb, dy * sb), pay = fmaf(dx, sb, -(dy * cb));
+    const float pbx = fmaf(dx, ca, dy * sa), pby = fmaf(dy, ca, -(dx * sa));
     float t2 = edges_inside3(pax, pay, c, s, ic, is, aic, ais, hwa, hha, hwb, hhb, wg, hg, true) +
                edges_inside3(pbx, pby, c, -s, ic, -is, aic, ais, hwb, hhb, hwa, hha, wp, hp, false);
     const bool near = fminf(fabsf(s), fabsf(c)) < kNearParallel;   // the two jitter steps cancelled: DESIGN.md §9
@@ -615,7 +620,7 @@ SPH_DEV float lean_finish(const float (&in1)[5], const float (&in2)[5], int mode
     const float a1 = wg * hg, a2 = wp * hp;
     const float base = mode == MODE_IOU ? (a1 + a2 - inter) : a1;
     float rb = fast_rcp(base);
-    rb = rb * (2.0f - base * rb);  // one Newton step: ~0.5 ulp quotient without the IEEE divide expansion
+    rb = rb * fmaf(-base, rb, 2.0f);  // one Newton step: ~0.5 ulp quotient without the IEEE divide expansion
     const float iou = fminf(fmaxf(inter * rb, 0.0f), 1.0f);
     return bad ? __builtin_nanf("") : iou;
 }

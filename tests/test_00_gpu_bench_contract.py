@@ -33,7 +33,7 @@ def check(d, steps, warmup):
     for k in KEYS:
         assert k in d, k
     assert d['unit'] == 'pairs/s' and d['n_gpus'] == 1 and d['steps'] == steps and d['warmup'] == warmup
-    assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None and d['dtype'] == 'f32'
+    assert d['higher_is_better'] is True and d['scaling'] == 'strong' and d['vs_baseline'] is None and d['dtype'] == 'f32'
     assert 'workload' in d['config'] and 'model' not in d['config']
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
@@ -47,10 +47,20 @@ def test_bench_single_process_contract():
     check(d, 200, 20)
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['unit'] == 'pairs/s' and c['cores'] >= 1 and c['value'] > 1e5 and 'sample' in c
+    assert c['reference_python']['cores'] == 8 and 'BASELINE.md' in c['reference_python']['source']
+    # the side measurements of round 2: the literal-contract (un-settled) figure, cold-HBM rotation, one 8 M-pair launch
+    u = d['unsettled']
+    assert u['untimed_steps_before_timing'] == 20 and u['ms_per_step'] >= 0.8 * d['ms_per_step']
+    cold, big = d['roofline']['cold'], d['roofline']['at_8m']
+    assert cold['working_set_bytes'] > 256 * 2 ** 20 and 0.05 < cold['frac'] < 1.0
+    assert big['pairs'] == 8_000_000 and 0.3 < big['frac'] < 1.0
+    assert d['config']['total_pairs'] == 1_000_000 and d['config']['gather'] is False
+    if d['roofline']['traffic'] is not None:
+        assert 'profiles/' in d['roofline']['traffic_source']
 
 
 def test_bench_under_torch_distributed_run_one_rank():
     d = run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
              '--master-port', '29577', 'bench.py', '--gpus', '1', '--steps', '100', '--warmup', '10', '--force-dist',
-             '--no-cpu-baseline'])
+             '--no-cpu-baseline', '--no-extras'])
     check(d, 100, 10)

@@ -26,6 +26,7 @@ for r in csv.DictReader(open(stats)):
         summary['kernels'][r['Name']] = {'calls': int(r['Calls']), 'avg_ns': float(r['AverageNs']),
                                          'min_ns': float(r['MinNs']), 'max_ns': float(r['MaxNs'])}
 counters = collections.defaultdict(lambda: collections.defaultdict(list))
+durations = collections.defaultdict(list)
 meta = {}
 for pas in ('pmc_fetch', 'pmc_write', 'pmc_sq'):
     files = glob.glob(os.path.join(src, pas, '*', '*_counter_collection.csv'))
@@ -34,6 +35,8 @@ for pas in ('pmc_fetch', 'pmc_write', 'pmc_sq'):
     for r in csv.DictReader(open(files[0])):
         if kernel_key in r['Kernel_Name']:
             counters[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
+            if pas == 'pmc_sq' and r['Counter_Name'] == 'SQ_ACTIVE_INST_VALU':
+                durations[r['Kernel_Name']].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
             meta[r['Kernel_Name']] = {'vgpr': int(r['VGPR_Count']), 'sgpr': int(r['SGPR_Count']),
                                       'lds': int(r['LDS_Block_Size']), 'scratch': int(r['Scratch_Size']),
                                       'grid': int(r['Grid_Size']), 'wg': int(r['Workgroup_Size'])}
@@ -50,10 +53,20 @@ for k, cs in counters.items():
         entry['hbm_bytes_per_launch'] = rd + wr
     if 'SQ_INSTS_VALU' in mean and 'SQ_WAVES' in mean:
         entry['valu_insts_per_wave'] = mean['SQ_INSTS_VALU'] / mean['SQ_WAVES']
+    if 'SQ_ACTIVE_INST_VALU' in mean and durations.get(k):
+        # SQ_ACTIVE_INST_VALU (quad-cycles, summed over waves) x 4 / (1024 SIMDs x cycles of the launch at
+        # the 2.4 GHz maximum clock).  NB it sums per-wave "a VALU instruction is in flight" time, so co-resident waves
+        # overlap in it: a share of issue capacity, not a busy fraction of the pipe.
+        d_ns = sum(durations[k]) / len(durations[k])
+        entry['pmc_pass_avg_ns'] = d_ns
+        entry['valu_active_frac'] = mean['SQ_ACTIVE_INST_VALU'] * 4 / (1024 * d_ns * 2.4)
 json.dump(summary, open(os.path.join(dst, f'{tag}_summary.json'), 'w'), indent=1)
 # bench.py reads the dominant kernel's measured traffic from here
 dom = max(summary['kernels'].items(), key=lambda kv: kv[1].get('calls', 0))
+cfg = {'pairs': int(os.environ.get('SPH2POB_PROFILE_PAIRS', 1000000)), 'variant': os.environ.get('SPH2POB_PROFILE_VARIANT', 'standard'),
+       'arithmetic': os.environ.get('SPH2POB_PROFILE_ARITHMETIC', 'fast')}
 json.dump({'iou_aligned': {'kernel': dom[0], 'hbm_bytes_per_launch': dom[1].get('hbm_bytes_per_launch'),
-                           'avg_ns': dom[1].get('avg_ns'), 'source': f'profiles/{tag}_summary.json'}},
+                           'valu_active_frac': dom[1].get('valu_active_frac'),
+                           'avg_ns': dom[1].get('avg_ns'), 'source': f'profiles/{tag}_summary.json', 'config': cfg}},
           open(os.path.join(dst, 'pmc_summary.json'), 'w'), indent=1)
 print(json.dumps(summary, indent=1)[:3000])
