@@ -233,10 +233,6 @@ SPH_DEV float near_parallel_inter(float px, float py, float c, float s, float hw
     return fmaxf((top - bot) - (lft - xl * H) - (xr * H - rgt), 0.0f);
 }
 
-// What phase 1 hands to phase 2 (kept in registers, or staged through the LDS survivor queue by the compacting kernel)
-struct FastRec { float N, D, Np, Dp, C, wg, hg, wp, hp, ga, gb; };
-enum : int { FAST_ZERO = 0, FAST_SURVIVOR = 1 };
-
 // Stage 0 (cull): a conservative bounding-circle test with hardware trig on the raw boxes.  Returns true when the
 // pair's IoU is exactly 0 (the two planar rectangles' circumscribed circles cannot touch, whatever the rounding of
 // the accurate path: the bound carries 1.5e-3 rad for both jitters + the reference's own rounding of A, and 1e-4 in
@@ -307,150 +303,13 @@ SPH_DEV bool fast_cull(const float (&g)[5], const float (&p)[5], int edge) {
 // trig by-products of stage 1 that the loss adjoint reuses
 struct FastTrig { float sg, cg, sp, cp, sD, cD; };
 
-// Stage 1: accurate trig on the jittered boxes, bearing numerators, and the exact early-out on accurate values.
-// CLAMPED: the boxes went through jitter_spherical (phi in [0, 180], theta in [0, 360] degrees), which lets the three
-// sincos calls use the cheap quadrant logic; the results are bit-identical either way on that range.
-template <int VARIANT, int DIM, bool CLAMPED = true>
-SPH_DEV int fast_phase1(const float (&b1)[5], const float (&b2)[5], int edge, FastRec& r, FastTrig* trig = nullptr) {
-#pragma clang fp contract(fast)
-    // degrees -> radians with the reference's rounding (torch.deg2rad: x * fl32(pi/180))
-    float thg = b1[0] * kDeg2Rad, phg = b1[1] * kDeg2Rad, thp = b2[0] * kDeg2Rad, php = b2[1] * kDeg2Rad;
-    r.wg = edge_length(b1[2] * kDeg2Rad, edge); r.hg = edge_length(b1[3] * kDeg2Rad, edge);
-    r.wp = edge_length(b2[2] * kDeg2Rad, edge); r.hp = edge_length(b2[3] * kDeg2Rad, edge);
-    r.ga = DIM == 5 ? b1[4] * kDeg2Rad : 0.0f;
-    r.gb = DIM == 5 ? b2[4] * kDeg2Rad : 0.0f;
-    float sg, cg, sp, cp, sD, h2;   // sD = sin(theta_p - theta_g), h2 = 1 - cos(theta_p - theta_g)
-    if (CLAMPED) {
-        sincos_colat(phg, sg, cg);
-        sincos_colat(php, sp, cp);
-        sin_vers_double(0.5f * (thp - thg), sD, h2);
-    } else {
-        float sh, ch;
-        sincos_r(phg, sg, cg);
-        sincos_r(php, sp, cp);
-        sincos_r(0.5f * (thp - thg), sh, ch);
-        sD = 2.0f * sh * ch;
-        h2 = 2.0f * sh * sh;
-    }
-    float q = sp * cg - cp * sg; // sin(phi_p - phi_g)
-    r.N = q - sp * cg * h2;  r.D = -sp * sD;
-    r.Np = q + sg * cp * h2; r.Dp = -sg * sD;
-    r.C = (cg * cp + sg * sp) - sg * sp * h2;
-    if (trig) { trig->sg = sg; trig->cg = cg; trig->sp = sp; trig->cp = cp; trig->sD = sD; trig->cD = 1.0f - h2; }
-    // exact early-out: circumscribed circles of the two planar rectangles cannot touch (margin covers both jitters
-    // and the reference's own rounding of A); 1 - R^2/2 + R^4/24 - R^6/720 <= cos R
-    // (r_g + r_p + 1.5e-3)^2 <= (d1 + d2 + 2 sqrt(d1 d2)) / 4 + 9.01e-3 for r_g + r_p < 3: one rsq, as in fast_cull
-    float d1 = r.wg * r.wg + r.hg * r.hg, d2 = r.wp * r.wp + r.hp * r.hp, prod = d1 * d2;
-    float R2 = 0.25f * (d1 + d2) + 0.5f * (prod * fast_rsq(prod)) + 9.01e-3f;
-    float cosR_lb = fmaf(fmaf(fmaf(-1.0f / 720.0f, R2, 1.0f / 24.0f), R2, -0.5f), R2, 1.0f);
-    if (R2 < 8.9f && r.C < cosR_lb) return FAST_ZERO;
-    return FAST_SURVIVOR;
-}
-
 // The two planar boxes after the rotated jitter, in the frame "P at the origin": T's centre is (dx, dy); angles as
-// (cos, sin).  g_* are gradient gates (false where a clamp / acos floor of the reference is active).
+// (cos, sin); (c, s) = cos / sin of (a_g - a_p).  g_* are gradient gates (false where a clamp / acos floor of the
+// reference is active) — only filled in when lean_front is asked for them.
 struct PlanarPair {
-    float dx, dy, ca, sa, cb, sb, wg, hg, wp, hp;
+    float dx, dy, ca, sa, cb, sb, wg, hg, wp, hp, c, s;
     bool g_A, g_ag, g_ap, g_wg, g_hg, g_wp, g_hp;
 };
-
-// Phase 2a: planar boxes as (cos, sin) + rotated jitter.
-template <int VARIANT, int DIM>
-SPH_DEV void fast_planar(const FastRec& r, PlanarPair& o) {
-#pragma clang fp contract(fast)
-    float wg = r.wg, hg = r.hg, wp = r.wp, hp = r.hp;
-    float S2 = r.N * r.N + r.D * r.D;
-    float iS = fast_rsq(S2);
-    float A = atan2_r(S2 * iS, r.C);
-    const float Amin = VARIANT == VARIANT_STANDARD ? 2.0f * kMinAng : kMinAng;
-    o.g_A = A > Amin;
-    A = fmaxf(A, Amin);
-    float ca = r.D * iS, sa = r.N * iS, cb = r.Dp * iS, sb = r.Np * iS;
-    if (!(S2 > 1e-30f)) {
-        // exactly coincident (or exactly antipodal) centres: the bearing is undefined (0/0).  N and D are products,
-        // not differences, so they stay meaningful down to ~1e-15 (e.g. two boxes clamped onto a pole: A ~ 1e-7 but
-        // the bearings still differ by the longitude difference); only a literal zero needs a convention: a = pi/2.
-        ca = 0.0f; sa = 1.0f; cb = 0.0f; sb = 1.0f;
-    }
-    if (DIM == 5) {
-        float sga, cga, sgb, cgb;
-        sincos_r(r.ga, sga, cga);
-        sincos_r(r.gb, sgb, cgb);
-        if (VARIANT == VARIANT_EFFICIENT) {  // floor, then a -= gamma
-            o.g_ag = fabsf(sa) >= kMinAng; o.g_ap = fabsf(sb) >= kMinAng;
-            angle_floor(ca, sa); angle_floor(cb, sb);
-        }
-        rot(ca, sa, cga, -sga);
-        rot(cb, sb, cgb, -sgb);
-        if (VARIANT == VARIANT_STANDARD) {   // d rotated first
-            o.g_ag = fabsf(sa) >= kMinAng; o.g_ap = fabsf(sb) >= kMinAng;
-            angle_floor(ca, sa); angle_floor(cb, sb);
-        }
-    } else {
-        o.g_ag = fabsf(sa) >= kMinAng; o.g_ap = fabsf(sb) >= kMinAng;
-        angle_floor(ca, sa);
-        angle_floor(cb, sb);
-    }
-    // ---- rotated jitter (sph_iou_api.py:222-242) on (x, w, h, a); decisions need real angles only when the
-    // two angles are within ~1.8e-3 of each other modulo 2*pi ----
-    const float e = (float)kEpsS, ea = (float)kEpsA;
-    float c = ca * cb + sa * sb, s = sa * cb - ca * sb;  // cos / sin of (a_g - a_p)
-    bool sim = (A < e) | (fabsf(wg - wp) < e) | (fabsf(hg - hp) < e);
-    bool close = false;
-    if (c > 0.5f && fabsf(s) < 2.0e-3f) {
-        float a1, a2;
-        if (DIM == 5 && VARIANT == VARIANT_EFFICIENT) {  // a = floor(atan2(N, D)) - gamma, not wrapped
-            float c1 = r.D * iS, s1 = r.N * iS, c2 = r.Dp * iS, s2 = r.Np * iS;
-            angle_floor(c1, s1);
-            angle_floor(c2, s2);
-            a1 = atan2_r(s1, c1) - r.ga;
-            a2 = atan2_r(s2, c2) - r.gb;
-        } else {
-            a1 = atan2_r(sa, ca);
-            a2 = atan2_r(sb, cb);
-        }
-        sim |= fabsf(a1 - a2) < e;
-        if (sim) { a1 += e; a2 += (float)(5 * kEpsS); }
-        close = fabsf(a1 - a2) < ea;
-    }
-    float dx = A, dy = 0.0f;
-    if (sim | close) {  // rare: constant rotations of (cos, sin) instead of new trig
-        if (sim) {
-            dx += e; dy += e;  // (x, y) += (e, e) vs (2e, 2e)
-            wg += (float)(2 * kEpsS); hg += (float)(2 * kEpsS); wp += e; hp += e;
-            rot(ca, sa, (float)0.99999999237921, (float)1.2345678e-4);    // cos/sin(e)
-            rot(cb, sb, (float)0.99999980948025, (float)6.172838610e-4);  // cos/sin(5e)
-        }
-        if (close) {
-            rot(ca, sa, (float)0.99999923792122, (float)1.2345674864e-3);  // cos/sin(ea)
-            rot(cb, sb, (float)0.99999695168547, (float)2.4691330913e-3);  // cos/sin(2ea)
-        }
-    }
-    o.g_wg = wg >= (float)(2 * kEpsA / 10); o.g_hg = hg >= (float)(2 * kEpsA / 10);
-    o.g_wp = wp >= (float)(kEpsA / 10);     o.g_hp = hp >= (float)(kEpsA / 10);
-    wg = fmaxf(wg, (float)(2 * kEpsA / 10)); hg = fmaxf(hg, (float)(2 * kEpsA / 10));
-    wp = fmaxf(wp, (float)(kEpsA / 10));     hp = fmaxf(hp, (float)(kEpsA / 10));
-    if (DIM == 5 && (fabsf(r.ga) > 3.1f || fabsf(r.gb) > 3.1f)) {
-        // |gamma| beyond 177 deg (outside any coder's range): the rotated jitter's angle clamp to
-        // [-2pi + 2ea, 2pi - ea] / [-2pi + ea, 2pi - 2ea] (sph_iou_api.py:239-240) may act on a = atan2(.) - gamma
-        const float twopi = 6.283185307179586f;
-        float a1 = atan2_r(sa, ca), a2 = atan2_r(sb, cb);  // wrapped representatives
-        if (VARIANT == VARIANT_EFFICIENT) {                // un-wrap to the reference's real value (|a| < 3*pi)
-            float est1 = -r.ga, est2 = -r.gb;              // a = beta - gamma, |beta| <= pi
-            a1 += twopi * rintf((est1 - a1) / twopi);
-            a2 += twopi * rintf((est2 - a2) / twopi);
-        }
-        float k1 = fminf(fmaxf(a1, -twopi + 2.0f * ea), twopi - ea), k2 = fminf(fmaxf(a2, -twopi + ea), twopi - 2.0f * ea);
-        if (k1 != a1 || k2 != a2) {
-            sincos_r(k1 - twopi * rintf(k1 / twopi), sa, ca);
-            sincos_r(k2 - twopi * rintf(k2 / twopi), sb, cb);
-            o.g_ag &= k1 == a1;
-            o.g_ap &= k2 == a2;
-        }
-    }
-    o.dx = dx; o.dy = dy; o.ca = ca; o.sa = sa; o.cb = cb; o.sb = sb;
-    o.wg = wg; o.hg = hg; o.wp = wp; o.hp = hp;
-}
 
 // "any lane of the wave": the rare branches of the finishing stage are guarded wave-uniformly, so a wave none of whose
 // lanes needs a branch skips its code with one scalar branch instead of executing it under an empty mask or paying
@@ -461,81 +320,81 @@ SPH_DEV void fast_planar(const FastRec& r, PlanarPair& o) {
 #define SPH_ANY_LANE(cond) (cond)
 #endif
 
-// Spherical jitter + stages 1 + 2 for one pair that survived the cull: clamp(IoU, 0, 1).
+// Stage 1 + planar boxes for one pair of spherically jittered boxes (degrees): the closed-form front end shared by the
+// IoU kernels (lean_finish) and the loss kernels (loss_front_fast) — one source for the planar pair, so that the IoU the
+// loss differentiates is the IoU the assigner sees.
 //
-// This is fast_phase1 + fast_planar + planar_area2 fused into one function whose COMMON path is straight-line code:
-// everything the reference only does for a few pairs in a thousand — the spherical jitter's shift, the acos floors,
-// the rotated jitter's decisions on real angles (2 atan2) and its bumps, the out-of-range gamma clamp, the
-// near-parallel safeguard — sits behind a wave-uniform guard.  Measured against the alternatives on MI355X
-// (profiles/r02b_ablation_*.log): always-on selects (round 1) 9.0 us per 1 M pairs; a lean path with rare
-// lanes re-run by the general form in place 12.1 us (0.7 % of the lanes, but every third wave holds one); the same
-// deferred to an index stack and finished per workgroup 11.0 us (one latency-bound pass per workgroup at the tail);
-// a separating-axis reject + second record stack in front of the clip 8.8 us with rare lanes dropped.
-// A NaN coordinate gives NaN, as the reference's torch.clamp chain does (sph_iou_api.py:86, :244-260).
-template <int VARIANT, int DIM>
-SPH_DEV float lean_finish(const float (&in1)[5], const float (&in2)[5], int mode, int edge) {
-    // explicit FMAs, contraction off (see rot): the same bits from every inlined copy
-    const float e = (float)kEpsS, e2 = (float)(2 * kEpsS), ea = (float)kEpsA;
-    const bool bad = pair_has_nan<DIM>(in1, in2);
-    // ---- jitter_spherical (sph_iou_api.py:244-260): shift only where `similar`, clamps always ----
-    float x1[5], x2[5];
-    bool similar = false;
-#pragma unroll
-    for (int k = 0; k < 5; k++) { x1[k] = in1[k]; x2[k] = in2[k]; }
-#pragma unroll
-    for (int k = 0; k < DIM; k++) similar |= fabsf(in1[k] - in2[k]) < e;
-    if (SPH_ANY_LANE(similar)) {
-        const float sh1 = similar ? e2 : 0.0f, sh2 = similar ? e : 0.0f;  // x - 0 == x exactly
-#pragma unroll
-        for (int k = 0; k < DIM; k++) { x1[k] = x1[k] - sh1; x2[k] = x2[k] + sh2; }
-    }
-    x1[0] = clampf(x1[0], e2, (float)(360.0 - kEpsS));
-    x2[0] = clampf(x2[0], e, (float)(360.0 - 2 * kEpsS));
-#pragma unroll
-    for (int k = 1; k < 4; k++) {
-        x1[k] = clampf(x1[k], e2, (float)(180.0 - kEpsS));
-        x2[k] = clampf(x2[k], e, (float)(180.0 - 2 * kEpsS));
-    }
-    if (DIM == 5) x2[4] = clampf(x2[4], (float)(-360.0 + 2 * kEpsS), (float)(360.0 - 2 * kEpsS));  // the two clamps of :256-258
-    // ---- stage 1 (fast_phase1): accurate trig on the jittered boxes, bearing numerators ----
+// The COMMON path is straight-line code: everything the reference only does for a few pairs in a thousand — the acos
+// floors, the rotated jitter's decisions on real angles (2 atan2) and its bumps, the out-of-range gamma clamp — sits
+// behind a wave-uniform guard.  Measured against the alternatives on MI355X (profiles/r02b_ablation_*.log, DESIGN.md
+// §9): always-on selects (round 1) 9.0 us per 1 M pairs; a lean path with rare lanes re-run by a general form in place
+// 12.1 us (0.7 % of the lanes, but every third wave holds one); the same deferred to an index stack and finished per
+// workgroup 11.0 us (one latency-bound pass per workgroup at the tail); a separating-axis reject + second record stack
+// in front of the clip 8.8 us with rare lanes dropped.
+// Arithmetic: explicit FMAs, contraction off (see rot) — the same bits from every inlined copy.
+// CLAMPED: the boxes went through jitter_spherical (phi in [0, 180], theta in [0, 360] degrees), which lets the three
+// sincos calls use the cheap quadrant logic (bit-identical on that range).  GATES: also fill in the gradient gates.
+template <int VARIANT, int DIM, bool GATES, bool CLAMPED = true>
+SPH_DEV void lean_front(const float (&x1)[5], const float (&x2)[5], int edge, PlanarPair& o, FastTrig* trig = nullptr) {
+    const float e = (float)kEpsS, ea = (float)kEpsA;
+    // ---- stage 1: accurate trig on the jittered boxes, bearing numerators; degrees -> radians with the reference's
+    // rounding (torch.deg2rad: x * fl32(pi/180)) ----
     const float thg = x1[0] * kDeg2Rad, phg = x1[1] * kDeg2Rad, thp = x2[0] * kDeg2Rad, php = x2[1] * kDeg2Rad;
     float wg = edge_length(x1[2] * kDeg2Rad, edge), hg = edge_length(x1[3] * kDeg2Rad, edge);
     float wp = edge_length(x2[2] * kDeg2Rad, edge), hp = edge_length(x2[3] * kDeg2Rad, edge);
-    float sg, cg, sp, cp, sD, h2;
-    sincos_colat(phg, sg, cg);
-    sincos_colat(php, sp, cp);
-    sin_vers_double(0.5f * (thp - thg), sD, h2);
+    float sg, cg, sp, cp, sD, h2;   // sD = sin(theta_p - theta_g), h2 = 1 - cos(theta_p - theta_g)
+    if (CLAMPED) {
+        sincos_colat(phg, sg, cg);
+        sincos_colat(php, sp, cp);
+        sin_vers_double(0.5f * (thp - thg), sD, h2);
+    } else {
+        float sh, ch;
+        sincos_r(phg, sg, cg);
+        sincos_r(php, sp, cp);
+        sincos_r(0.5f * (thp - thg), sh, ch);
+        const float t = sh * ch;
+        sD = t + t;
+        h2 = 2.0f * sh * sh;
+    }
     const float spcg = sp * cg, sgcp = sg * cp, sgsp = sg * sp;
     const float q = spcg - sgcp;                     // sin(phi_p - phi_g)
     const float N = fmaf(-spcg, h2, q), D = -sp * sD;
     const float Np = fmaf(sgcp, h2, q), Dp = -sg * sD;
     const float C = fmaf(-sgsp, h2, fmaf(cg, cp, sgsp));
-    // ---- planar boxes as (cos, sin) (fast_planar) ----
+    if (trig) { trig->sg = sg; trig->cg = cg; trig->sp = sp; trig->cp = cp; trig->sD = sD; trig->cD = 1.0f - h2; }
+    // ---- planar boxes as (cos, sin) ----
     const float S2 = fmaf(N, N, D * D);
     const float iS = fast_rsq(S2);
     float A = atan2_r(S2 * iS, C);
-    A = fmaxf(A, VARIANT == VARIANT_STANDARD ? 2.0f * kMinAng : kMinAng);
+    const float Amin = VARIANT == VARIANT_STANDARD ? 2.0f * kMinAng : kMinAng;
+    if (GATES) o.g_A = A > Amin;
+    A = fmaxf(A, Amin);
     float ca = D * iS, sa = N * iS, cb = Dp * iS, sb = Np * iS;
-    if (SPH_ANY_LANE(!(S2 > 1e-30f))) {   // exactly coincident / antipodal centres: bearing undefined, convention a = pi/2
+    if (SPH_ANY_LANE(!(S2 > 1e-30f))) {
+        // exactly coincident (or exactly antipodal) centres: the bearing is undefined (0/0).  N and D are products,
+        // not differences, so they stay meaningful down to ~1e-15 (e.g. two boxes clamped onto a pole: A ~ 1e-7 but
+        // the bearings still differ by the longitude difference); only a literal zero needs a convention: a = pi/2.
         if (!(S2 > 1e-30f)) { ca = 0.0f; sa = 1.0f; cb = 0.0f; sb = 1.0f; }
     }
     float ga = 0.0f, gb = 0.0f;
+    // the reference's sign * |acos(clamp(cos a))| floors |a| and |pi - a| at kMinAng (angle_floor)
+    auto floors = [&]() {
+        const bool fa = fabsf(sa) < kMinAng, fb = fabsf(sb) < kMinAng;
+        if (GATES) { o.g_ag = !fa; o.g_ap = !fb; }
+        if (SPH_ANY_LANE(fa | fb)) { angle_floor(ca, sa); angle_floor(cb, sb); }
+    };
     if (DIM == 5) {
         ga = x1[4] * kDeg2Rad;
         gb = x2[4] * kDeg2Rad;
         float sga, cga, sgb, cgb;
         sincos_r(ga, sga, cga);
         sincos_r(gb, sgb, cgb);
-        if (VARIANT == VARIANT_EFFICIENT) {  // floor, then a -= gamma
-            if (SPH_ANY_LANE((fabsf(sa) < kMinAng) | (fabsf(sb) < kMinAng))) { angle_floor(ca, sa); angle_floor(cb, sb); }
-        }
+        if (VARIANT == VARIANT_EFFICIENT) floors();   // floor, then a -= gamma
         rot(ca, sa, cga, -sga);
         rot(cb, sb, cgb, -sgb);
-        if (VARIANT == VARIANT_STANDARD) {   // d rotated first
-            if (SPH_ANY_LANE((fabsf(sa) < kMinAng) | (fabsf(sb) < kMinAng))) { angle_floor(ca, sa); angle_floor(cb, sb); }
-        }
+        if (VARIANT == VARIANT_STANDARD) floors();    // d rotated first
     } else {
-        if (SPH_ANY_LANE((fabsf(sa) < kMinAng) | (fabsf(sb) < kMinAng))) { angle_floor(ca, sa); angle_floor(cb, sb); }
+        floors();
     }
     // ---- rotated jitter (sph_iou_api.py:222-242) on (x, w, h, a); its decisions need real angles only when the two
     // angles are within ~1.8e-3 of each other modulo 2 pi ----
@@ -579,6 +438,10 @@ SPH_DEV float lean_finish(const float (&in1)[5], const float (&in2)[5], int mode
             s = fmaf(sa, cb, -(ca * sb));
         }
     }
+    if (GATES) {
+        o.g_wg = wg >= (float)(2 * kEpsA / 10); o.g_hg = hg >= (float)(2 * kEpsA / 10);
+        o.g_wp = wp >= (float)(kEpsA / 10);     o.g_hp = hp >= (float)(kEpsA / 10);
+    }
     wg = fmaxf(wg, (float)(2 * kEpsA / 10)); hg = fmaxf(hg, (float)(2 * kEpsA / 10));
     wp = fmaxf(wp, (float)(kEpsA / 10));     hp = fmaxf(hp, (float)(kEpsA / 10));
     if (DIM == 5) {
@@ -599,25 +462,59 @@ SPH_DEV float lean_finish(const float (&in1)[5], const float (&in2)[5], int mode
                     sincos_r(k2 - twopi * rintf(k2 / twopi), sb, cb);
                     c = fmaf(ca, cb, sa * sb);
                     s = fmaf(sa, cb, -(ca * sb));
+                    if (GATES) { o.g_ag &= k1 == a1; o.g_ap &= k2 == a2; }
                 }
             }
         }
     }
+    o.dx = dx; o.dy = dy; o.ca = ca; o.sa = sa; o.cb = cb; o.sb = sb; o.c = c; o.s = s;
+    o.wg = wg; o.hg = hg; o.wp = wp; o.hp = hp;
+}
+
+// Spherical jitter + stages 1 + 2 for one pair that survived the cull: clamp(IoU, 0, 1).  The spherical jitter's shift
+// and the near-parallel safeguard are guarded like lean_front's rare branches.  A NaN coordinate gives NaN, as the
+// reference's torch.clamp chain does (sph_iou_api.py:86, :244-260).
+template <int VARIANT, int DIM>
+SPH_DEV float lean_finish(const float (&in1)[5], const float (&in2)[5], int mode, int edge) {
+    const float e = (float)kEpsS, e2 = (float)(2 * kEpsS);
+    const bool bad = pair_has_nan<DIM>(in1, in2);
+    // ---- jitter_spherical (sph_iou_api.py:244-260): shift only where `similar`, clamps always ----
+    float x1[5], x2[5];
+    bool similar = false;
+#pragma unroll
+    for (int k = 0; k < 5; k++) { x1[k] = in1[k]; x2[k] = in2[k]; }
+#pragma unroll
+    for (int k = 0; k < DIM; k++) similar |= fabsf(in1[k] - in2[k]) < e;
+    if (SPH_ANY_LANE(similar)) {
+        const float sh1 = similar ? e2 : 0.0f, sh2 = similar ? e : 0.0f;  // x - 0 == x exactly
+#pragma unroll
+        for (int k = 0; k < DIM; k++) { x1[k] = x1[k] - sh1; x2[k] = x2[k] + sh2; }
+    }
+    x1[0] = clampf(x1[0], e2, (float)(360.0 - kEpsS));
+    x2[0] = clampf(x2[0], e, (float)(360.0 - 2 * kEpsS));
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+        x1[k] = clampf(x1[k], e2, (float)(180.0 - kEpsS));
+        x2[k] = clampf(x2[k], e, (float)(180.0 - 2 * kEpsS));
+    }
+    if (DIM == 5) x2[4] = clampf(x2[4], (float)(-360.0 + 2 * kEpsS), (float)(360.0 - 2 * kEpsS));  // the two clamps of :256-258
+    PlanarPair q;
+    lean_front<VARIANT, DIM, false>(x1, x2, edge, q);
     // ---- stage 2: boundary integral of the two rectangles (P at the origin, T at (dx, dy)) ----
     const float kBig = 1e18f;
-    const float ic = fminf(fmaxf(fast_rcp(c), -kBig), kBig), is = fminf(fmaxf(fast_rcp(s), -kBig), kBig);
+    const float ic = fminf(fmaxf(fast_rcp(q.c), -kBig), kBig), is = fminf(fmaxf(fast_rcp(q.s), -kBig), kBig);
     const float aic = fabsf(ic), ais = fabsf(is);
-    const float hwa = 0.5f * wg, hha = 0.5f * hg, hwb = 0.5f * wp, hhb = 0.5f * hp;
-    const float pax = -fmaf(dx, cb, dy * sb), pay = fmaf(dx, sb, -(dy * cb));
-    const float pbx = fmaf(dx, ca, dy * sa), pby = fmaf(dy, ca, -(dx * sa));
-    float t2 = edges_inside3(pax, pay, c, s, ic, is, aic, ais, hwa, hha, hwb, hhb, wg, hg, true) +
-               edges_inside3(pbx, pby, c, -s, ic, -is, aic, ais, hwb, hhb, hwa, hha, wp, hp, false);
-    const bool near = fminf(fabsf(s), fabsf(c)) < kNearParallel;   // the two jitter steps cancelled: DESIGN.md §9
+    const float hwa = 0.5f * q.wg, hha = 0.5f * q.hg, hwb = 0.5f * q.wp, hhb = 0.5f * q.hp;
+    const float pax = -fmaf(q.dx, q.cb, q.dy * q.sb), pay = fmaf(q.dx, q.sb, -(q.dy * q.cb));
+    const float pbx = fmaf(q.dx, q.ca, q.dy * q.sa), pby = fmaf(q.dy, q.ca, -(q.dx * q.sa));
+    float t2 = edges_inside3(pax, pay, q.c, q.s, ic, is, aic, ais, hwa, hha, hwb, hhb, q.wg, q.hg, true) +
+               edges_inside3(pbx, pby, q.c, -q.s, ic, -is, aic, ais, hwb, hhb, hwa, hha, q.wp, q.hp, false);
+    const bool near = fminf(fabsf(q.s), fabsf(q.c)) < kNearParallel;   // the two jitter steps cancelled: DESIGN.md §9
     if (SPH_ANY_LANE(near)) {
-        if (near) t2 = 2.0f * near_parallel_inter(pax, pay, c, s, hwa, hha, hwb, hhb);
+        if (near) t2 = 2.0f * near_parallel_inter(pax, pay, q.c, q.s, hwa, hha, hwb, hhb);
     }
     const float inter = 0.5f * fmaxf(t2, 0.0f);
-    const float a1 = wg * hg, a2 = wp * hp;
+    const float a1 = q.wg * q.hg, a2 = q.wp * q.hp;
     const float base = mode == MODE_IOU ? (a1 + a2 - inter) : a1;
     float rb = fast_rcp(base);
     rb = rb * fmaf(-base, rb, 2.0f);  // one Newton step: ~0.5 ulp quotient without the IEEE divide expansion

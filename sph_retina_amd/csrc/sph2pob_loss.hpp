@@ -78,7 +78,7 @@ struct PlanarGrad { float x, w, h, a; };  // d(.)/d(x, w, h, a) of one planar bo
 // rotated jitter in the frame "pred box at the origin" (target centre = (dx, dy)), gradient gates of every clamp /
 // acos floor on the way, and the trig of the jittered spherical inputs for the chain rule.
 struct LossFront {
-    float dx, dy, ca, sa, cb, sb, wg, hg, wp, hp;
+    float dx, dy, ca, sa, cb, sb, wg, hg, wp, hp, c, s;   // (c, s) = cos / sin of (a_P - a_T)
     bool g_A, g_ag, g_ap, g_wg, g_hg, g_wp, g_hp;
     float sg, cg, sp, cp, sD, cD;  // sin/cos(phi_g), sin/cos(phi_p), sin/cos(theta_p - theta_g)
 };
@@ -92,6 +92,7 @@ SPH_DEV void loss_front_reference(const float (&b1)[5], const float (&b2)[5], Lo
     jitter_rotated(P, T);
     f.dx = T.x - P.x; f.dy = T.y - P.y;
     f.sa = sinf(P.a); f.ca = cosf(P.a); f.sb = sinf(T.a); f.cb = cosf(T.a);
+    f.c = f.ca * f.cb + f.sa * f.sb; f.s = f.sa * f.cb - f.ca * f.sb;
     f.wg = P.w; f.hg = P.h; f.wp = T.w; f.hp = T.h;
     {   // rotated-jitter clamp gates (sph_iou_api.py:237-240: in-place clamp_ => zero gradient outside)
         const float e = (float)kEpsS, e2 = (float)(2 * kEpsS), e5 = (float)(5 * kEpsS);
@@ -140,15 +141,13 @@ namespace sph2pob {
 template <int DIM, int VARIANT = VARIANT_STANDARD>
 SPH_DEV void loss_front_fast(const float (&b1)[5], const float (&b2)[5], LossFront& f, int edge = EDGE_ARC,
                              bool rot_jitter = true) {
-    FastRec r;
     FastTrig t;
-    // rot_jitter == "the caller ran jitter_spherical first", i.e. the angles are clamped into the range of the cheap trig
-    if (rot_jitter) fast_phase1<VARIANT, DIM, true>(b1, b2, edge, r, &t);
-    else fast_phase1<VARIANT, DIM, false>(b1, b2, edge, r, &t);
     PlanarPair q;
-    fast_planar<VARIANT, DIM>(r, q);
+    // rot_jitter == "the caller ran jitter_spherical first", i.e. the angles are clamped into the range of the cheap trig
+    if (rot_jitter) lean_front<VARIANT, DIM, true, true>(b1, b2, edge, q, &t);
+    else lean_front<VARIANT, DIM, true, false>(b1, b2, edge, q, &t);
     if (!rot_jitter) { q.g_wg = q.g_hg = q.g_wp = q.g_hp = true; }
-    f.dx = q.dx; f.dy = q.dy; f.ca = q.ca; f.sa = q.sa; f.cb = q.cb; f.sb = q.sb;
+    f.dx = q.dx; f.dy = q.dy; f.ca = q.ca; f.sa = q.sa; f.cb = q.cb; f.sb = q.sb; f.c = q.c; f.s = q.s;
     f.wg = q.wg; f.hg = q.hg; f.wp = q.wp; f.hp = q.hp;
     f.g_A = q.g_A; f.g_ag = q.g_ag; f.g_ap = q.g_ap; f.g_wg = q.g_wg; f.g_hg = q.g_hg; f.g_wp = q.g_wp; f.g_hp = q.g_hp;
     f.sg = t.sg; f.cg = t.cg; f.sp = t.sp; f.cp = t.cp; f.sD = t.sD; f.cD = t.cD;
@@ -255,7 +254,7 @@ SPH_DEV float pair_loss(const float (&pred)[5], const float (&target)[5], int lo
     struct { float x, y, w, h; } P{0.0f, 0.0f, f.wg, f.hg}, T{dx, dy, f.wp, f.hp};
 
     // ---- planar IoU (value of mmcv diff_iou_rotated_2d: sphdet/iou/diff_iou_rotated.py:325-343) ----
-    float c = ca * cb + sa * sb, s = sa * cb - ca * sb;
+    const float c = f.c, s = f.s;
     // clamped reciprocals: exactly parallel edges (s == 0 after the jitter bumps) give finite, correctly ordered bounds
     float ic = fminf(fmaxf(fast_rcp(c), -1e18f), 1e18f), is = fminf(fmaxf(fast_rcp(s), -1e18f), 1e18f);
     float hwa = 0.5f * P.w, hha = 0.5f * P.h, hwb = 0.5f * T.w, hhb = 0.5f * T.h;
