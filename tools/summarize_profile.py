@@ -53,13 +53,14 @@ for k, cs in counters.items():
         entry['hbm_bytes_per_launch'] = rd + wr
     if 'SQ_INSTS_VALU' in mean and 'SQ_WAVES' in mean:
         entry['valu_insts_per_wave'] = mean['SQ_INSTS_VALU'] / mean['SQ_WAVES']
-    if 'SQ_ACTIVE_INST_VALU' in mean and durations.get(k):
-        # SQ_ACTIVE_INST_VALU (quad-cycles, summed over waves) x 4 / (1024 SIMDs x cycles of the launch at
-        # the 2.4 GHz maximum clock).  NB it sums per-wave "a VALU instruction is in flight" time, so co-resident waves
-        # overlap in it: a share of issue capacity, not a busy fraction of the pipe.
-        d_ns = sum(durations[k]) / len(durations[k])
-        entry['pmc_pass_avg_ns'] = d_ns
-        entry['valu_active_frac'] = mean['SQ_ACTIVE_INST_VALU'] * 4 / (1024 * d_ns * 2.4)
+    if 'SQ_ACTIVE_INST_VALU' in mean and entry.get('avg_ns'):
+        # SQ_ACTIVE_INST_VALU (quad-cycles, summed over waves) x 4 / (1024 SIMDs x cycles of one launch at
+        # the 2.4 GHz maximum clock; launch duration = the un-perturbed kernel-trace average, the counter passes
+        # serialise launches and run them slower).  NB the counter sums per-wave "a VALU instruction is in flight" time
+        # (~4 cycles per instruction whatever its kind), so it measures issue slots used, not a busy fraction of the pipe.
+        entry['valu_active_frac'] = mean['SQ_ACTIVE_INST_VALU'] * 4 / (1024 * entry['avg_ns'] * 2.4)
+        if durations.get(k):
+            entry['pmc_pass_avg_ns'] = sum(durations[k]) / len(durations[k])
 json.dump(summary, open(os.path.join(dst, f'{tag}_summary.json'), 'w'), indent=1)
 # bench.py reads the dominant kernel's measured traffic from here
 dom = max(summary['kernels'].items(), key=lambda kv: kv[1].get('calls', 0))
