@@ -108,6 +108,17 @@ int sph2pob_transform_bwd_f32(const float* b1, const float* b2, const float* gra
                               void* stream);
 
 /*
+ * Planar rotated-rectangle IoU on GIVEN planar boxes (x, y, w, h, a [rad]) — the op the reference obtains from mmcv
+ * (`mmcv.ops.box_iou_rotated`, call sites sphdet/iou/sph_iou_api.py:79, :193; the vendored value-equivalent
+ * `diff_iou_rotated_2d`, sphdet/iou/diff_iou_rotated.py:325-343, called directly by tests/test_all_ious.py:22-24).
+ * aligned != 0: out[i] = IoU(p1[i], p2[i]), m == n; aligned == 0: out[i * n + j] = IoU(p1[i], p2[j]) (rows = p1).
+ * mode: SPH2POB_MODE_IOU | SPH2POB_MODE_IOF.  No jitter and no clamp (as the mmcv op): exactly parallel edges are
+ * handled by the boundary integral's clamped reciprocals, nearly parallel ones (|sin| < 2.5e-4) in double.
+ */
+int sph2pob_planar_iou_f32(const float* p1, int64_t m, const float* p2, int64_t n, float* out, int aligned, int mode,
+                           void* stream);
+
+/*
  * Sph2PobIoULoss element values: loss[i] = scale * w_i * L(pred[i], target[i]), L = 1 - IoU | GIoU | DIoU | CIoU
  * form; scale carries loss_weight (sph2pob_iou_loss.py:49).
  * Replaces Sph2PobTransfrom.new_forward (sphdet/losses/sph2pob_transform.py:24-35: clone, spherical jitter,
@@ -130,6 +141,18 @@ int sph2pob_loss_fwd_f32(const float* pred, const float* target, const float* we
 int sph2pob_loss_bwd_f32(const float* pred, const float* target, const float* weight, int weight_dim,
                          const float* grad_out, int grad_stride, float scale, float* grad_pred, float* grad_target,
                          int64_t n, int box_dim, int loss_mode, float eps, void* stream);
+
+/*
+ * The same loss REDUCED in one go: out[0] = scale * sum_i w_i * L(pred[i], target[i]) — the forward kernel leaves one
+ * partial sum per workgroup in `workspace` (no element buffer is written or re-read), a second launch adds the partials
+ * in a fixed order (bitwise reproducible, no float atomics).  scale carries loss_weight and the 1 / n | 1 / (avg_factor +
+ * eps) of weight_reduce_loss (mmdet/models/losses/utils.py:47-58).  workspace: device buffer of at least
+ * sph2pob_loss_sum_workspace_floats(n) floats.  Backward: sph2pob_loss_bwd_f32 with grad_stride 0 and the same scale.
+ */
+int64_t sph2pob_loss_sum_workspace_floats(int64_t n);
+int sph2pob_loss_fwd_sum_f32(const float* pred, const float* target, const float* weight, int weight_dim, float scale,
+                             float* out, float* workspace, int64_t n, int box_dim, int loss_mode, float eps,
+                             void* stream);
 
 /*
  * out[0] = scale * sum(x[0..n)) — deterministic two-pass tree (bitwise reproducible, no float atomics); the

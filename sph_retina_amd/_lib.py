@@ -33,6 +33,7 @@ SIGNATURES = {
     'sph2pob_iou_aligned_f32': [_c_f32p, _c_f32p, _c_f32p, _i64, _int, _int, _int, _int, _int, ctypes.c_void_p],
     'sph2pob_iou_pairwise_f32': [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _int, _int, _int, _int, _int,
                                  ctypes.c_void_p],
+    'sph2pob_planar_iou_f32': [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _int, _int, ctypes.c_void_p],
     'sph2pob_transform_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _int, _int, _int, _int,
                               ctypes.c_void_p],
     'sph2pob_transform_bwd_f32': [_c_f32p] * 6 + [_i64, _int, _int, _int, _int, ctypes.c_void_p],
@@ -41,6 +42,9 @@ SIGNATURES = {
                              ctypes.c_void_p],
     'sph2pob_loss_bwd_f32': [_c_f32p, _c_f32p, _c_f32p, _int, _c_f32p, _int, ctypes.c_float, _c_f32p, _c_f32p, _i64,
                              _int, _int, ctypes.c_float, ctypes.c_void_p],
+    'sph2pob_loss_sum_workspace_floats': [_i64],
+    'sph2pob_loss_fwd_sum_f32': [_c_f32p, _c_f32p, _c_f32p, _int, ctypes.c_float, _c_f32p, _c_f32p, _i64, _int, _int,
+                                 ctypes.c_float, ctypes.c_void_p],
     'sph2pob_sum_workspace_floats': [],
     'sph2pob_sum_f32': [_c_f32p, _i64, ctypes.c_float, _c_f32p, _c_f32p, ctypes.c_void_p],
     'sph2pob_assign_workspace_bytes': [_i64, _i64],
@@ -63,7 +67,7 @@ SIGNATURES = {
     'sph2pob_obb_l1_bwd_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_float, _c_f32p, _c_f32p, _i64, _int,
                                ctypes.c_void_p],
 }
-_RESTYPES = {'sph2pob_target_arch': ctypes.c_char_p, 'sph2pob_error_string': ctypes.c_char_p,
+_RESTYPES = {'sph2pob_loss_sum_workspace_floats': ctypes.c_int64, 'sph2pob_target_arch': ctypes.c_char_p, 'sph2pob_error_string': ctypes.c_char_p,
              'sph2pob_nms_workspace_bytes': ctypes.c_int64, 'sph2pob_nms_segmented_workspace_bytes': ctypes.c_int64, 'sph2pob_assign_workspace_bytes': ctypes.c_int64}
 
 ABI_VERSION = 1

@@ -73,6 +73,16 @@ def stream_of(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+def raw_stream_of(device):
+    """The same handle as a plain integer (what a ctypes `c_void_p` parameter accepts without building an object)."""
+    idx = device.index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    if _raw_stream is not None:
+        return _raw_stream(idx)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 _FN_CACHE = {}
 
 
@@ -94,12 +104,32 @@ _WORKSPACES = {}
 
 
 def sum_workspace(device):
-    """Per-device scratch of the deterministic two-pass sum (stream-ordered reuse is safe: one stream per device
-    in the callers; a different stream gets its own buffer)."""
+    """Scratch of the deterministic two-pass sum, one buffer per (device, stream): stream-ordered reuse is safe within a
+    stream, a second stream gets its own.  A buffer first needed while the stream is CAPTURING is not cached: it would
+    come from the graph's private pool and outlive it in this global table (round-1 VERDICT #6); the capture gets a plain
+    temporary, which the pool keeps alive for the graph like any other tensor allocated inside the capture."""
     idx = torch.cuda.current_device() if device.index is None else device.index
     key = (idx, _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream)
     ws = _WORKSPACES.get(key)
     if ws is None:
-        ws = _WORKSPACES[key] = torch.empty((_lib.lib().sph2pob_sum_workspace_floats(),), dtype=torch.float32,
-                                            device=device)
+        ws = torch.empty((_lib.lib().sph2pob_sum_workspace_floats(),), dtype=torch.float32, device=device)
+        if not torch.cuda.is_current_stream_capturing():
+            _WORKSPACES[key] = ws
+    return ws
+
+
+_LOSS_WS = {}
+
+
+def loss_sum_workspace(device, n):
+    """Per-(device, stream) partial-sum scratch of `sph2pob_loss_fwd_sum_f32`, grown on demand (never shrunk); the same
+    capture rule as sum_workspace."""
+    idx = torch.cuda.current_device() if device.index is None else device.index
+    key = (idx, raw_stream_of(device))
+    need = (n + 255) // 256 + 1024
+    ws = _LOSS_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty((max(need, 8192),), dtype=torch.float32, device=device)
+        if not torch.cuda.is_current_stream_capturing():
+            _LOSS_WS[key] = ws
     return ws

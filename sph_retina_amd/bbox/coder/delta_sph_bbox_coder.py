@@ -106,8 +106,16 @@ class _DeltaSphCoderBase:
         assert pred_bboxes.size(0) == bboxes.size(0)
         if pred_bboxes.ndim == 3:
             assert pred_bboxes.size(1) == bboxes.size(1)
-        if pred_bboxes.ndim != 2:  # the reference raises for batched decode as well (:104)
-            raise NotImplementedError('batched (B, N, ...) decode is not implemented; decode per image')
+        if pred_bboxes.ndim == 3:
+            # batched (B, N, d) anchors with (B, N, num_classes * d) deltas.  The reference's decode raises here
+            # (`raise NotImplemented(...)`, delta_xywh_sph_bbox_coder.py:104) and its delta2bbox mis-reads a 3-D input
+            # (num_classes = N // 4, :226); boxes are independent, so the batch is decoded as one (B * N, ...) launch.
+            b, n = pred_bboxes.shape[:2]
+            flat = delta2bbox(bboxes.reshape(b * n, -1), pred_bboxes.reshape(b * n, -1), self.means, self.stds, max_shape,
+                              wh_ratio_clip, self.clip_border, self.add_ctr_clamp, self.ctr_clamp, box_dim=self.box_dim)
+            return flat.reshape(b, n, -1)
+        if pred_bboxes.ndim != 2:
+            raise ValueError(f'decode expects (N, C*d) or (B, N, C*d) deltas, got {tuple(pred_bboxes.shape)}')
         return delta2bbox(bboxes, pred_bboxes, self.means, self.stds, max_shape, wh_ratio_clip, self.clip_border,
                           self.add_ctr_clamp, self.ctr_clamp, box_dim=self.box_dim)
 

@@ -21,6 +21,23 @@ _CALCULATORS = {'sph2pob_efficient': 'efficient', 'sph2pob_efficient_iou': 'effi
                 'unbiased_iou': 'unbiased', 'naive_iou': 'naive'}  # sph_nms.py:9-14
 
 
+def _variant_of(iou_calculator):
+    """Calculator spelling -> kernel variant.  The reference passes either the registry string (SphNMS, sph_nms.py:8-16)
+    or the IoU FUNCTION itself (`sph_nms_op(boxes, scores, thr, sph2pob_efficient_iou)`, :19, :62): both are accepted;
+    a function is mapped by its name."""
+    if isinstance(iou_calculator, str):
+        name = iou_calculator
+    elif callable(iou_calculator):
+        name = getattr(iou_calculator, '__name__', '')
+    else:
+        raise TypeError(f'iou_calculator must be a name or one of the sph IoU functions, got {type(iou_calculator).__name__}')
+    if name in _CALCULATORS:
+        return _CALCULATORS[name]
+    if name in _CALCULATORS.values():   # already a variant name ('efficient', ...): SphNMS hands these over
+        return name
+    raise TypeError(f'Not supported iou_calculator: {name!r} (accepted: {sorted(_CALCULATORS)})')
+
+
 def _nms_sorted(boxes_sorted, cls_sorted, iou_threshold, variant):
     """keep flags (uint8, K) for boxes sorted by (class, -score)."""
     k, dim = boxes_sorted.shape
@@ -36,7 +53,10 @@ def _nms_sorted(boxes_sorted, cls_sorted, iou_threshold, variant):
     max_seg = k if cls_sorted is None or k <= 8192 else int(torch.unique_consecutive(cls_sorted, return_counts=True)[1].max())
     limit = lib.sph2pob_nms_max_boxes()
     if max_seg > limit:
-        raise ValueError(f'sph nms supports at most {limit} boxes per class, got {max_seg}')
+        # the sweep keeps one class segment's "removed" bit-vector in LDS: 32 704 boxes per class; the
+        # reference has no limit but needs one host round trip per kept box (minutes at this size)
+        raise ValueError(f'sph nms supports at most {limit} boxes per class segment, got {max_seg}; '
+                         'lower nms_pre / raise score_thr, or split the call by class')
     ws = torch.empty((lib.sph2pob_nms_segmented_workspace_bytes(k, max_seg) // 8,), dtype=torch.int64, device=dev)
     G.call('sph2pob_nms_segmented_f32', dev, G.ptr(boxes_sorted), G.ptr(cls_sorted), ctypes.c_int64(k), dim,
            G.VARIANTS[variant], ctypes.c_float(iou_threshold), ctypes.c_int64(max_seg), G.ptr(ws), G.ptr(keep),
@@ -46,7 +66,7 @@ def _nms_sorted(boxes_sorted, cls_sorted, iou_threshold, variant):
 
 def sph_nms_op(boxes, scores, iou_threshold, iou_calculator='sph2pob_efficient'):
     """Single-class greedy NMS -> indices of kept boxes in descending-score order (reference :62-74)."""
-    variant = _CALCULATORS[iou_calculator] if isinstance(iou_calculator, str) else iou_calculator
+    variant = _variant_of(iou_calculator)
     assert boxes.size(1) in [4, 5]
     G.require_hip(boxes, scores)
     order = torch.argsort(scores, descending=True, stable=True)
@@ -70,7 +90,7 @@ def sph_batched_nms(boxes, scores, idxs, nms_cfg, iou_calculator='efficient', cl
     by_score = torch.argsort(scores, descending=True, stable=True)
     order = by_score[torch.argsort(idxs[by_score], stable=True)]
     flags = _nms_sorted(G.as_f32(boxes[order]), idxs[order].to(torch.int64).contiguous(), float(iou_threshold),
-                        iou_calculator)
+                        _variant_of(iou_calculator))
     total_mask = torch.zeros(scores.shape, dtype=torch.bool, device=scores.device)
     total_mask[order] = flags.bool()
     keep = total_mask.nonzero(as_tuple=False).view(-1)           # ascending original index (reference :49)

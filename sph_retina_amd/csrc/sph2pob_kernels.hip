@@ -87,7 +87,10 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_kernel(const float* __rest
 //     26 % of the pairs overlap, 40 % pass the cull): 8.80 us against 8.55 us without the second stack — the 35 % idle
 //     clip lanes cost less than the extra LDS round trip and the longer per-wave dependency chain;
 //   * rare lanes (jitter decisions, floors, near-parallel: 0.7 % of the survivors) re-run by a general form in place
-//     12.1 us, deferred to an index stack and finished once per workgroup 11.0 us — hence lean_finish's guarded blocks.
+//     12.1 us, deferred to an index stack and finished once per workgroup 11.0 us — hence lean_front's guarded blocks;
+//   * no carried state at all: one wave per 128-pair chunk, cull both slices, compact, finish (one pass at 81 % lane
+//     use, no workgroup merge, no barrier): 8.84 us against 8.96 us here at 1 M pairs, 56.9 against 55.1 us at 8 M;
+//     one lane per pair without compaction 10.3 us / 66.0 us (profiles/r02f_ab_*.log).
 constexpr int kQCap = 128;                    // per-wave stack capacity (<= 63 carried + 64 pushed)
 template <int DIM>
 struct WaveQueue {
@@ -115,8 +118,11 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // ARC: rbb_edge == 'arc' folded at compile time (the chord / tangent forms pull ocml's sinf / tanf argument reduction
 // into the cull and the finishing stage: 8 copies of ~100 instructions the common launch never executes)
-template <int VARIANT, int DIM, bool PREFETCH, bool ARC>
-__global__ __launch_bounds__(kBlock, DIM == 4 ? 7 : 5) void iou_aligned_compact_kernel(const float* __restrict__ b1,
+// REF: finish with the reference-order arithmetic (pair_iou) instead of the closed-form core: the cull is exact for it as
+// well (disjoint planar rectangles give exactly 0 in the reference), so `set_arithmetic('reference')` pays its ~3x VALU
+// only for the survivors, on full waves.
+template <int VARIANT, int DIM, bool PREFETCH, bool ARC, bool REF = false>
+__global__ __launch_bounds__(kBlock, REF ? 4 : (DIM == 4 ? 7 : 5)) void iou_aligned_compact_kernel(const float* __restrict__ b1,
                                                                                       const float* __restrict__ b2,
                                                                                       float* __restrict__ out, int n,
                                                                                       int mode, int edge_arg) {
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(kBlock, DIM == 4 ? 7 : 5) void iou_aligned_compact_
             wave_lds_fence();
             float u1[5], u2[5];
             const int j = queue_load<DIM>(q, count + lane, u1, u2);
-            out[j] = lean_finish<VARIANT, DIM>(u1, u2, mode, edge);
+            out[j] = REF ? pair_iou<VARIANT, DIM>(u1, u2, mode, edge, ANGLE_EQUATOR) : lean_finish<VARIANT, DIM>(u1, u2, mode, edge);
         }
     };
     auto fetch = [&](int sl, float (&x)[5], float (&y)[5]) {
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(kBlock, DIM == 4 ? 7 : 5) void iou_aligned_compact_
             if (k >= c0) { k -= c0; w = 1; if (k >= c1) { k -= c1; w = 2; if (k >= c2) { k -= c2; w = 3; } } }
             float u1[5], u2[5];
             const int j = queue_load<DIM>(queues[w], k, u1, u2);
-            out[j] = lean_finish<VARIANT, DIM>(u1, u2, mode, edge);
+            out[j] = REF ? pair_iou<VARIANT, DIM>(u1, u2, mode, edge, ANGLE_EQUATOR) : lean_finish<VARIANT, DIM>(u1, u2, mode, edge);
         }
     }
 }
@@ -282,6 +288,18 @@ __global__ __launch_bounds__(kBlock) void transform_kernel(const float* __restri
 }
 
 
+// ---- planar rotated IoU on given planar boxes (mmcv box_iou_rotated / diff_iou_rotated_2d values) ----
+__global__ __launch_bounds__(kBlock) void planar_iou_kernel(const float* __restrict__ p1, int64_t m, const float* __restrict__ p2,
+                                                           int64_t n, float* __restrict__ out, int aligned, int mode) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = aligned ? j : (int64_t)blockIdx.y;
+    if (j >= n) return;
+    const float* a = p1 + i * 5;
+    const float* b = p2 + j * 5;
+    const PBox A{a[0], a[1], a[2], a[3], a[4]}, B{b[0], b[1], b[2], b[3], b[4]};
+    out[aligned ? j : i * n + j] = planar_iou(A, B, mode);
+}
+
 // ---- loss: per-element weight = mean over weight_dim columns (reference: sph2pob_transform.py:32-34 widens a
 // (n,4) weight with its own mean, OBBIoULoss.forward then takes weight.mean(-1): sph2pob_iou_loss.py:48) ----
 template <int DIM>
@@ -316,6 +334,30 @@ __global__ __launch_bounds__(kBlock) void loss_fwd_kernel(const float* __restric
     float l = pair_loss<DIM, false, FAST>(x, y, loss_mode, eps, &io, gx, gy);
     loss[i] = l * w;
     if (iou) iou[i] = io;
+}
+
+__device__ __forceinline__ float block_sum(float v);
+// forward + per-workgroup partial sum (reduction 'mean' / 'sum'): no element buffer
+template <int DIM, bool FAST>
+__global__ __launch_bounds__(kBlock) void loss_fwd_sum_kernel(const float* __restrict__ pred,
+                                                             const float* __restrict__ target,
+                                                             const float* __restrict__ weight, int wd,
+                                                             float* __restrict__ partial, int64_t n, int loss_mode,
+                                                             float eps) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    float v = 0.0f;
+    const bool live = i < n;
+    const float w = live ? element_weight<DIM>(weight, wd, i) : 0.0f;
+    if (__ballot(w != 0.0f) != 0) {   // an all-zero-weight wave contributes exact zeros (see loss_fwd_kernel)
+        if (live) {
+            float x[5], y[5], gx[5], gy[5];
+            load_box<DIM>(pred, i, x);
+            load_box<DIM>(target, i, y);
+            v = pair_loss<DIM, false, FAST>(x, y, loss_mode, eps, nullptr, gx, gy) * w;
+        }
+    }
+    const float r = block_sum(v);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
 template <int DIM, bool FAST>
@@ -693,7 +735,7 @@ struct AlignedLaunch {
     const float *b1, *b2; float* out; int64_t n; int mode, edge, angle; hipStream_t s; bool fast = true;
     template <int V, int D> int run() {
         dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-        if (fast && V < 2 && angle == SPH2POB_ANGLE_EQUATOR && n < ((int64_t)1 << 31) - 64 && !g_no_compact) {
+        if (V < 2 && angle == SPH2POB_ANGLE_EQUATOR && n < ((int64_t)1 << 31) - 64 && !g_no_compact) {
             // persistent-style grid.  Measured on MI355X (tools/sweep_slices.sh): every CU must hold the same number of
             // workgroups (1 303 workgroups = 5.09 per CU take 12 % longer than 1 536 = 6 per CU); 6 per CU (24 waves per CU)
             // is the best or within noise of the best from 125 k to 8 M pairs; small launches want one slice per wave
@@ -709,9 +751,10 @@ struct AlignedLaunch {
             if (g_wgs_per_cu > 0) wgs = kCUs * g_wgs_per_cu;
             if (wgs < 1) wgs = 1;
             constexpr int VV = V >= 2 ? 0 : V;
-#define SPH_PIPE(PF, ARC) hipLaunchKernelGGL((iou_aligned_compact_kernel<VV, D, PF, ARC>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge)
-            if (edge == SPH2POB_EDGE_ARC) { if (g_prefetch) SPH_PIPE(true, true); else SPH_PIPE(false, true); }
-            else { if (g_prefetch) SPH_PIPE(true, false); else SPH_PIPE(false, false); }
+#define SPH_PIPE(PF, ARC, REF) hipLaunchKernelGGL((iou_aligned_compact_kernel<VV, D, PF, ARC, REF>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge)
+            if (!fast) { if (wgs > kCUs * 4) wgs = kCUs * 4; SPH_PIPE(true, false, true); }   // reference-order finish: 4 waves per SIMD
+            else if (edge == SPH2POB_EDGE_ARC) { if (g_prefetch) SPH_PIPE(true, true, false); else SPH_PIPE(false, true, false); }
+            else { if (g_prefetch) SPH_PIPE(true, false, false); else SPH_PIPE(false, false, false); }
 #undef SPH_PIPE
         } else if (fast && V < 2 && angle == SPH2POB_ANGLE_EQUATOR)
             hipLaunchKernelGGL((iou_aligned_kernel<V >= 2 ? 0 : V, D, true>), grid, dim3(kBlock), 0, s, b1, b2, out, n, mode, edge, angle);
@@ -821,6 +864,29 @@ int sph2pob_transform_f32(const float* b1, const float* b2, float* planar1, floa
                     TransformLaunch{b1, b2, planar1, planar2, n, edge, angle, jitter, (hipStream_t)stream});
 }
 
+int sph2pob_planar_iou_f32(const float* p1, int64_t m, const float* p2, int64_t n, float* out, int aligned, int mode,
+                           void* stream) {
+    if (mode < 0 || mode > 1) return SPH2POB_ERR_OPTION;
+    if (m < 0 || n < 0 || m > kMaxElems || n > kMaxElems || (aligned && m != n)) return SPH2POB_ERR_SIZE;
+    if (m == 0 || n == 0) return SPH2POB_OK;
+    if (!p1 || !p2 || !out) return SPH2POB_ERR_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned bx = (unsigned)((n + kBlock - 1) / kBlock);
+    if (aligned) {
+        hipLaunchKernelGGL(planar_iou_kernel, dim3(bx), dim3(kBlock), 0, s, p1, m, p2, n, out, 1, mode);
+        return launch_status();
+    }
+    const int64_t kMaxRows = 65535;   // grid.y limit: walk the rows in slabs
+    for (int64_t r0 = 0; r0 < m; r0 += kMaxRows) {
+        const int64_t rows = m - r0 < kMaxRows ? m - r0 : kMaxRows;
+        hipLaunchKernelGGL(planar_iou_kernel, dim3(bx, (unsigned)rows), dim3(kBlock), 0, s, p1 + r0 * 5, rows, p2, n,
+                           out + r0 * n, 0, mode);
+        const int rc = launch_status();
+        if (rc) return rc;
+    }
+    return SPH2POB_OK;
+}
+
 int sph2pob_loss_fwd_f32(const float* pred, const float* target, const float* weight, int weight_dim, float scale,
                          float* loss, float* iou, int64_t n, int box_dim, int loss_mode_flags, float eps, void* stream) {
     const int loss_mode = loss_mode_flags & 0xff;
@@ -861,6 +927,39 @@ int sph2pob_loss_bwd_f32(const float* pred, const float* target, const float* we
     if (box_dim == 4) { if (fast) SPH_LOSS_BWD(4, true); else SPH_LOSS_BWD(4, false); }
     else { if (fast) SPH_LOSS_BWD(5, true); else SPH_LOSS_BWD(5, false); }
 #undef SPH_LOSS_BWD
+    return launch_status();
+}
+
+int64_t sph2pob_loss_sum_workspace_floats(int64_t n) { return (n + kBlock - 1) / kBlock + kSumBlocks; }
+
+int sph2pob_loss_fwd_sum_f32(const float* pred, const float* target, const float* weight, int weight_dim, float scale,
+                             float* out, float* workspace, int64_t n, int box_dim, int loss_mode_flags, float eps,
+                             void* stream) {
+    const int loss_mode = loss_mode_flags & 0xff;
+    const bool fast = !(loss_mode_flags & SPH2POB_FLAG_REFERENCE_ORDER);
+    if (loss_mode_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER)) return SPH2POB_ERR_OPTION;
+    if (box_dim != 4 && box_dim != 5) return SPH2POB_ERR_DIM;
+    if (loss_mode < 0 || loss_mode > 3) return SPH2POB_ERR_OPTION;
+    if (weight && weight_dim != 1 && weight_dim != box_dim) return SPH2POB_ERR_OPTION;
+    if (n < 0 || n > kMaxElems) return SPH2POB_ERR_SIZE;
+    if (!out || !workspace || (n > 0 && (!pred || !target))) return SPH2POB_ERR_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nb = (n + kBlock - 1) / kBlock;
+    if (nb > 0) {
+        dim3 grid((unsigned)nb);
+#define SPH_LOSS_FWDS(D, F) \
+        hipLaunchKernelGGL((loss_fwd_sum_kernel<D, F>), grid, dim3(kBlock), 0, s, pred, target, weight, weight_dim, workspace, n, loss_mode, eps)
+        if (box_dim == 4) { if (fast) SPH_LOSS_FWDS(4, true); else SPH_LOSS_FWDS(4, false); }
+        else { if (fast) SPH_LOSS_FWDS(5, true); else SPH_LOSS_FWDS(5, false); }
+#undef SPH_LOSS_FWDS
+    }
+    if (nb <= 65536) {   // one workgroup adds the partials in a fixed order
+        hipLaunchKernelGGL(sum_pass2, dim3(1), dim3(kBlock), 0, s, workspace, (int)nb, scale, out);
+    } else {             // very large batches: the two-pass tree over the partials
+        float* ws2 = workspace + nb;
+        hipLaunchKernelGGL(sum_pass1, dim3(kSumBlocks), dim3(kBlock), 0, s, workspace, nb, ws2);
+        hipLaunchKernelGGL(sum_pass2, dim3(1), dim3(kBlock), 0, s, ws2, kSumBlocks, scale, out);
+    }
     return launch_status();
 }
 

@@ -10,8 +10,6 @@ sph2pob_iou_loss.py:43-48), `avg_factor` semantics (mmdet/models/losses/utils.py
 follow the reference.  Difference: the reference's all-zero-weight shortcut (:36-39) needs a device->host sync
 (`torch.any`); here zero weights simply produce a zero loss with zero gradients on the normal path.
 """
-import ctypes
-
 import torch
 import torch.nn as nn
 
@@ -27,30 +25,39 @@ def _mode_code(mode):
 _F32_EPS = float(torch.finfo(torch.float32).eps)
 
 
+def _f32c(t):
+    """The tensor itself when it already is contiguous fp32 (the common case: no detach / copy objects on the hot
+    path), else a contiguous fp32 copy."""
+    return t if t.dtype is torch.float32 and t.is_contiguous() else G.as_f32(t.detach())
+
+
 class _Sph2PobLossFunction(torch.autograd.Function):
-    """(pred, target[, weight]) -> weighted element losses (reduce=False) or their sum (reduce=True)."""
+    """(pred, target[, weight]) -> scale * weighted element losses (reduce=False) or scale * their sum (reduce=True).
+    One node in the autograd graph: `scale` carries loss_weight AND the 1 / n | 1 / (avg_factor + eps) of
+    weight_reduce_loss, so 'mean' costs no extra torch op (and no extra backward node) on top of the two forward launches
+    (loss + per-workgroup partial sums, final sum) and the one backward launch."""
 
     @staticmethod
     def forward(ctx, pred, target, weight, mode_c, eps, scale, reduce):
         G.require_hip(pred, target)
         n, dim = pred.shape
-        p, t = G.as_f32(pred.detach()), G.as_f32(target.detach())
-        w = G.as_f32(weight.detach()) if weight is not None else None
+        p, t = _f32c(pred), _f32c(target)
+        w = _f32c(weight) if weight is not None else None
         wd = 0 if w is None else (1 if w.dim() == 1 else w.size(1))
+        wp = w.data_ptr() if w is not None and n else None
         dev = p.device
-        elem = torch.empty((n,), dtype=torch.float32, device=dev)
-        if n:
-            G.call('sph2pob_loss_fwd_f32', dev, G.ptr(p), G.ptr(t), G.ptr(w), wd, ctypes.c_float(scale), G.ptr(elem),
-                   ctypes.c_void_p(0), ctypes.c_int64(n), dim, mode_c, ctypes.c_float(eps), G.stream_of(p))
+        stream = G.raw_stream_of(dev)
+        if reduce:
+            out = torch.empty((), dtype=torch.float32, device=dev)
+            G.call('sph2pob_loss_fwd_sum_f32', dev, p.data_ptr() if n else None, t.data_ptr() if n else None, wp, wd, scale,
+                   out.data_ptr(), G.loss_sum_workspace(dev, n).data_ptr(), n, dim, mode_c, eps, stream)
+        else:
+            out = torch.empty((n,), dtype=torch.float32, device=dev)
+            if n:
+                G.call('sph2pob_loss_fwd_f32', dev, p.data_ptr(), t.data_ptr(), wp, wd, scale, out.data_ptr(), None, n, dim,
+                       mode_c, eps, stream)
         ctx.save_for_backward(p, t, w)
         ctx.meta = (mode_c, eps, scale, reduce, wd, pred.dtype, target.dtype)
-        if not reduce:
-            return elem
-        if not n:
-            return torch.zeros((), dtype=torch.float32, device=dev)
-        out = torch.empty((), dtype=torch.float32, device=dev)
-        G.call('sph2pob_sum_f32', dev, G.ptr(elem), ctypes.c_int64(n), ctypes.c_float(1.0),
-               ctypes.c_void_p(out.data_ptr()), G.ptr(G.sum_workspace(dev)), G.stream_of(p))
         return out
 
     @staticmethod
@@ -59,14 +66,18 @@ class _Sph2PobLossFunction(torch.autograd.Function):
         mode_c, eps, scale, reduce, wd, pdt, tdt = ctx.meta
         n, dim = p.shape
         need_p, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        g = G.as_f32(grad_out)
+        g = _f32c(grad_out)
         gp = torch.empty_like(p)
         gt = torch.empty_like(t) if need_t else None
         if n:
-            G.call('sph2pob_loss_bwd_f32', p.device, G.ptr(p), G.ptr(t), G.ptr(w), wd, G.ptr(g), 0 if reduce else 1,
-                   ctypes.c_float(scale), G.ptr(gp), G.ptr(gt), ctypes.c_int64(n), dim, mode_c, ctypes.c_float(eps),
-                   G.stream_of(p))
-        return (gp.to(pdt) if need_p else None), (gt.to(tdt) if need_t else None), None, None, None, None, None
+            G.call('sph2pob_loss_bwd_f32', p.device, p.data_ptr(), t.data_ptr(), w.data_ptr() if w is not None else None, wd,
+                   g.data_ptr(), 0 if reduce else 1, scale, gp.data_ptr(), gt.data_ptr() if need_t else None, n, dim, mode_c,
+                   eps, G.raw_stream_of(p.device))
+        if pdt is not torch.float32:
+            gp = gp.to(pdt)
+        if need_t and tdt is not torch.float32:
+            gt = gt.to(tdt)
+        return (gp if need_p else None), (gt if need_t else None), None, None, None, None, None
 
 
 def sph2pob_iou_loss(pred, target, weight=None, mode='iou', eps=1e-6, reduction='mean', avg_factor=None,
@@ -81,12 +92,18 @@ def sph2pob_iou_loss(pred, target, weight=None, mode='iou', eps=1e-6, reduction=
     if reduction == 'none':
         return _Sph2PobLossFunction.apply(pred, target, weight, _mode_code(mode), float(eps), float(loss_weight), False)
     assert reduction in ('mean', 'sum')
-    total = _Sph2PobLossFunction.apply(pred, target, weight, _mode_code(mode), float(eps), float(loss_weight), True)
     if reduction == 'sum':
-        return total
-    if avg_factor is None:
-        return total / n if n else total * float('nan')  # torch: mean of an empty tensor is nan
-    return total / (avg_factor + _F32_EPS)
+        scale = float(loss_weight)
+    elif avg_factor is None:
+        if n == 0:   # torch: mean of an empty tensor is nan
+            return _Sph2PobLossFunction.apply(pred, target, weight, _mode_code(mode), float(eps), 1.0, True) * float('nan')
+        scale = float(loss_weight) / n
+    elif isinstance(avg_factor, torch.Tensor):   # a device scalar (e.g. an all-reduced positive count): no host sync
+        total = _Sph2PobLossFunction.apply(pred, target, weight, _mode_code(mode), float(eps), float(loss_weight), True)
+        return total / (avg_factor + _F32_EPS)
+    else:
+        scale = float(loss_weight) / (float(avg_factor) + _F32_EPS)
+    return _Sph2PobLossFunction.apply(pred, target, weight, _mode_code(mode), float(eps), scale, True)
 
 
 class OBBIoULoss(nn.Module):

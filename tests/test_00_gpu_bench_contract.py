@@ -64,3 +64,20 @@ def test_bench_under_torch_distributed_run_one_rank():
              '--master-port', '29577', 'bench.py', '--gpus', '1', '--steps', '100', '--warmup', '10', '--force-dist',
              '--no-cpu-baseline', '--no-extras'])
     check(d, 100, 10)
+
+
+@pytest.mark.parametrize('scenario', ['recipe', 'stale'])
+def test_graph_capture_of_backward_into_a_leaf(scenario):
+    """`loss.backward()` accumulating into a leaf's .grad, captured into a hipGraph and replayed (round-1 VERDICT #6: that
+    pattern ended in a segmentation fault inside torch's capture_end and the test was rewritten around it).  Run in a child
+    process so that a crash of the runtime is a test failure with its output, not the end of the test session.
+    'recipe' = torch's documented whole-step capture (grads dropped before the capture); 'stale' = the leaf's .grad already
+    exists from an eager backward on another stream (what round 1 had).  tools/graph_capture_backward.py explains both."""
+    import torch
+    if torch.cuda.is_initialized():
+        pytest.skip('the GPU is already initialised in this process: not starting child processes from it')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, os.path.join('tools', 'graph_capture_backward.py'), scenario], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert 'replay ok' in out.stdout

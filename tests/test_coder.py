@@ -129,3 +129,26 @@ def test_gpu_decode_feeds_loss_and_gradients_reach_deltas(oracle):
     with torch.no_grad():
         stepped = deltas - 0.5 * deltas.grad / deltas.grad.abs().max()
     assert S.Sph2PobIoULoss(mode='ciou')(coder.decode(cu(anchors), stepped), cu(gts)) < loss
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dim,cls', CASES)
+def test_gpu_batched_decode_equals_per_image_decode(dim, cls):
+    """(B, N, d) anchors with (B, N, C*d) deltas in one launch (the reference's decode raises there,
+    delta_xywh_sph_bbox_coder.py:104): identical to decoding image by image, gradients included."""
+    import sph_retina_amd as S
+    g = load_golden('coder')
+    k = f'd{dim}_'
+    coder = getattr(S, cls)(target_means=tuple(g[k + 'means']), target_stds=tuple(g[k + 'stds']))
+    a = torch.from_numpy(g[k + 'anchors']).cuda()
+    d = torch.from_numpy(g[k + 'deltas']).cuda()
+    n = (a.size(0) // 3) * 3
+    ab, db = a[:n].reshape(3, n // 3, dim), d[:n].reshape(3, n // 3, dim).clone().requires_grad_(True)
+    out = coder.decode(ab, db)
+    assert out.shape == (3, n // 3, dim)
+    per = torch.stack([coder.decode(ab[i], db[i].detach()) for i in range(3)])
+    assert torch.equal(out.detach(), per)
+    out.sum().backward()
+    d2 = d[:n].clone().requires_grad_(True)
+    coder.decode(a[:n], d2).sum().backward()
+    assert torch.equal(db.grad.reshape(n, dim), d2.grad)

@@ -59,12 +59,15 @@ def test_mmdet_known_answers(A):
     assert none.gt_inds.numel() == 0 and none.labels.numel() == 0
 
 
-def test_config4_call_pattern_end_to_end(A, oracle):
-    """RetinaNet assigner of the reference config (pos 0.5 / neg 0.4 / min_pos 0): 64 GT x ~98k anchors."""
+@pytest.mark.parametrize('hw,count', [((512, 1024), 98208), ((1024, 2048), 392832)])
+def test_config4_call_pattern_end_to_end(A, oracle, hw, count):
+    """RetinaNet assigner of the reference config (pos 0.5 / neg 0.4 / min_pos 0): 64 GT x 98 208 anchors (the
+    reference's default 512 x 1024 ERP: the "~100k" of BASELINE configs[3]) and x 392 832 (the literal 1024 x 2048 grid)."""
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
     from bench_configs import retina_anchors
-    anchors = retina_anchors()
+    anchors = retina_anchors(*hw)
+    assert anchors.size(0) == count
     g = torch.Generator().manual_seed(0)
     u = torch.rand((64, 4), generator=g)
     gt = torch.stack([u[:, 0] * 360, 20 + u[:, 1] * 140, 5 + u[:, 2] * 85, 5 + u[:, 3] * 85], 1).cuda()

@@ -66,6 +66,14 @@ def test_single_class_op_and_edge_cases(N, oracle):
     keep = N.sph_nms_op(cu(b), cu(s), 0.3)
     okeep = oracle.nms_op(b, s, 0.3)
     assert len(set(keep.tolist()) ^ set(okeep.tolist())) <= 1
+    # the reference hands the IoU FUNCTION to sph_nms_op (sph_nms.py:19, :62): accepted, mapped by name
+    import sph_retina_amd as S
+    assert torch.equal(N.sph_nms_op(cu(b), cu(s), 0.3, S.sph2pob_efficient_iou), keep)
+    assert torch.equal(N.sph_nms_op(cu(b), cu(s), 0.3, 'sph2pob_efficient_iou'), keep)
+    with pytest.raises(TypeError):
+        N.sph_nms_op(cu(b), cu(s), 0.3, len)
+    with pytest.raises(TypeError):
+        N.sph_nms_op(cu(b), cu(s), 0.3, 42)
     # idempotence: NMS of the survivors keeps all of them
     kb, ks = cu(b)[keep], cu(s)[keep]
     again = N.sph_nms_op(kb, ks, 0.3)

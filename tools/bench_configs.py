@@ -72,10 +72,11 @@ def config3(n=1_000_000):
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     nn, null = ctypes.c_int64(n), ctypes.c_void_p(0)
 
+    ws2 = torch.empty(lib.sph2pob_loss_sum_workspace_floats(n), device='cuda')
+
     def abi_step():
-        lib.sph2pob_loss_fwd_f32(G.ptr(p_), G.ptr(t_), null, 0, ctypes.c_float(1.0), G.ptr(elem), null, nn, 5, 3,
-                                 ctypes.c_float(1e-6), st)
-        lib.sph2pob_sum_f32(G.ptr(elem), nn, ctypes.c_float(1.0 / n), ctypes.c_void_p(out.data_ptr()), G.ptr(ws), st)
+        lib.sph2pob_loss_fwd_sum_f32(G.ptr(p_), G.ptr(t_), null, 0, ctypes.c_float(1.0 / n), ctypes.c_void_p(out.data_ptr()),
+                                     G.ptr(ws2), nn, 5, 3, ctypes.c_float(1e-6), st)
         lib.sph2pob_loss_bwd_f32(G.ptr(p_), G.ptr(t_), null, 0, ctypes.c_void_p(one.data_ptr()), 0, ctypes.c_float(1.0 / n),
                                  G.ptr(gp), null, nn, 5, 3, ctypes.c_float(1e-6), st)
     ta = timeit(abi_step)
@@ -84,7 +85,8 @@ def config3(n=1_000_000):
             'pairs_per_s_c_abi': n / ta, 'pairs_per_s_autograd': n / t,
             'algorithmic_bytes_per_pair': 108, 'hbm_GBps_c_abi': 108 * n / ta / 1e9,
             'hbm_frac_of_8TBps_c_abi': 108 * n / ta / 8e12,
-            'note': 'the torch.autograd step is host-bound (~120 us of Python/autograd per call); kernels: see c_abi'}
+            'note': 'c_abi = loss_fwd_sum (forward + per-workgroup partial sums) + final sum + loss_bwd through the C ABI; '
+                    'autograd = the same three launches behind torch.autograd (one Function node), host-bound'}
 
 
 def retina_anchors(h=512, w=1024):
@@ -105,8 +107,8 @@ def retina_anchors(h=512, w=1024):
     return a.cuda()
 
 
-def config4():
-    anchors = retina_anchors()
+def config4(h=512, w=1024):
+    anchors = retina_anchors(h, w)
     g = torch.Generator().manual_seed(0)
     u = torch.rand((64, 4), generator=g)
     gt = torch.stack([u[:, 0] * 360, 20 + u[:, 1] * 140, 5 + u[:, 2] * 85, 5 + u[:, 3] * 85], 1).cuda()
@@ -137,7 +139,7 @@ def config4():
     t_nms = timeit(lambda: nms(nb, ns, ni, cfg), reps=20)
     t_nms1 = timeit(lambda: nms(nb, ns, torch.zeros_like(ni), cfg), reps=10)
     m, n = ov.shape
-    return {'config': 'configs[3]: MaxIoUAssigner overlaps 64 GT x %d anchors (512x1024 ERP grid) + SphNMS 5000 boxes' % n,
+    return {'config': 'configs[3]: MaxIoUAssigner overlaps 64 GT x %d anchors (%dx%d ERP grid) + SphNMS 5000 boxes' % (n, h, w),
             'pairs': m * n, 'iou_matrix_ms': t_iou * 1e3, 'pairs_per_s': m * n / t_iou,
             'iou_plus_torch_max_argmax_ms': t_assign * 1e3, 'fused_assign_total_ms': t_fused * 1e3, 'frac_pairs_overlapping': float((ov > 0).float().mean()),
             'nms_5000x37cls_ms': t_nms * 1e3, 'nms_5000_single_class_ms': t_nms1 * 1e3}
@@ -219,5 +221,7 @@ def variants(n=1_000_000):
 
 
 if __name__ == '__main__':
-    for fn in (config3, config4, coder, unbiased, variants):
+    # config4 twice: the reference's default 512 x 1024 ERP (98 208 anchors: the "~100k" of BASELINE configs[3]) and the
+    # literal 1024 x 2048 grid (392 832 anchors, SURVEY §8d "secondary")
+    for fn in (config3, config4, lambda: config4(1024, 2048), coder, unbiased, variants):
         print(json.dumps(fn()), flush=True)
