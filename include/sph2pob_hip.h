@@ -155,6 +155,21 @@ int sph2pob_loss_fwd_sum_f32(const float* pred, const float* target, const float
                              void* stream);
 
 /*
+ * Forward AND gradients in one pass (the training call: the backward kernel recomputes the whole forward, so when the
+ * gradient will be asked for anyway the loss value is a by-product of it): writes the loss elements (loss, may be NULL)
+ * and / or their sum (out_sum + workspace as in sph2pob_loss_fwd_sum_f32, may be NULL), and
+ *     grad_pred[i, :]   = scale * w_i * dL_i / dpred[i, :]        (n, box_dim)
+ *     grad_target[i, :] = scale * w_i * dL_i / dtarget[i, :]      (optional, may be NULL)
+ * i.e. the gradients for an upstream gradient of 1.  torch's backward then only scales them:
+ * sph2pob_loss_grad_scale_f32: out[i, :] = stash[i, :] * grad_out[i * grad_stride]  (grad_stride 0: one scalar).
+ */
+int sph2pob_loss_fwd_grad_f32(const float* pred, const float* target, const float* weight, int weight_dim, float scale,
+                              float* loss, float* out_sum, float* workspace, float* grad_pred, float* grad_target,
+                              int64_t n, int box_dim, int loss_mode, float eps, void* stream);
+int sph2pob_loss_grad_scale_f32(const float* stash, const float* grad_out, int grad_stride, float* out, int64_t n,
+                                int box_dim, void* stream);
+
+/*
  * out[0] = scale * sum(x[0..n)) — deterministic two-pass tree (bitwise reproducible, no float atomics); the
  * reduction step of weight_reduce_loss (mmdet/models/losses/utils.py:47-55).  workspace: device buffer of at
  * least sph2pob_sum_workspace_floats() floats.

@@ -45,6 +45,9 @@ SIGNATURES = {
     'sph2pob_loss_sum_workspace_floats': [_i64],
     'sph2pob_loss_fwd_sum_f32': [_c_f32p, _c_f32p, _c_f32p, _int, ctypes.c_float, _c_f32p, _c_f32p, _i64, _int, _int,
                                  ctypes.c_float, ctypes.c_void_p],
+    'sph2pob_loss_fwd_grad_f32': [_c_f32p, _c_f32p, _c_f32p, _int, ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
+                                  _i64, _int, _int, ctypes.c_float, ctypes.c_void_p],
+    'sph2pob_loss_grad_scale_f32': [_c_f32p, _c_f32p, _int, _c_f32p, _i64, _int, ctypes.c_void_p],
     'sph2pob_sum_workspace_floats': [],
     'sph2pob_sum_f32': [_c_f32p, _i64, ctypes.c_float, _c_f32p, _c_f32p, ctypes.c_void_p],
     'sph2pob_assign_workspace_bytes': [_i64, _i64],

@@ -393,6 +393,54 @@ __global__ __launch_bounds__(kBlock) void loss_bwd_kernel(const float* __restric
     }
 }
 
+// forward + gradients for an upstream gradient of 1 (+ per-workgroup partial sum of the loss when `partial`)
+template <int DIM, bool FAST>
+__global__ __launch_bounds__(kBlock) void loss_fwd_grad_kernel(const float* __restrict__ pred,
+                                                              const float* __restrict__ target,
+                                                              const float* __restrict__ weight, int wd, float scale,
+                                                              float* __restrict__ loss, float* __restrict__ partial,
+                                                              float* __restrict__ gpred, float* __restrict__ gtarget,
+                                                              int64_t n, int loss_mode, float eps) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < n;
+    const float w = live ? scale * element_weight<DIM>(weight, wd, i) : 0.0f;
+    float x[5], y[5], gx[5], gy[5], l = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 5; k++) gx[k] = gy[k] = 0.0f;
+    if (__ballot(w != 0.0f) != 0) {   // an all-zero-weight wave: zero loss, zero gradients, no geometry
+        if (live) {
+            load_box<DIM>(pred, i, x);
+            load_box<DIM>(target, i, y);
+            l = pair_loss<DIM, true, FAST>(x, y, loss_mode, eps, nullptr, gx, gy) * w;
+        }
+    }
+    if (live) {
+        if (loss) loss[i] = l;
+        if (DIM == 4) {
+            reinterpret_cast<float4*>(gpred)[i] = make_float4(w * gx[0], w * gx[1], w * gx[2], w * gx[3]);
+            if (gtarget) reinterpret_cast<float4*>(gtarget)[i] = make_float4(w * gy[0], w * gy[1], w * gy[2], w * gy[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 5; k++) gpred[i * 5 + k] = w * gx[k];
+            if (gtarget) {
+#pragma unroll
+                for (int k = 0; k < 5; k++) gtarget[i * 5 + k] = w * gy[k];
+            }
+        }
+    }
+    if (partial) {   // workgroup-uniform
+        const float r = block_sum(live ? l : 0.0f);
+        if (threadIdx.x == 0) partial[blockIdx.x] = r;
+    }
+}
+// out[i, :] = stash[i, :] * g[i * stride]: the whole of torch's backward after loss_fwd_grad_kernel
+__global__ __launch_bounds__(kBlock) void grad_scale_kernel(const float* __restrict__ stash, const float* __restrict__ g,
+                                                           int stride, float* __restrict__ out, int64_t total, int dim) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= total) return;
+    out[e] = stash[e] * g[stride ? (e / dim) : 0];
+}
+
 // ---- deterministic two-pass sum (bitwise reproducible losses; no float atomics) ----
 constexpr int kSumBlocks = 1024;
 __device__ __forceinline__ float block_sum(float v) {
@@ -960,6 +1008,53 @@ int sph2pob_loss_fwd_sum_f32(const float* pred, const float* target, const float
         hipLaunchKernelGGL(sum_pass1, dim3(kSumBlocks), dim3(kBlock), 0, s, workspace, nb, ws2);
         hipLaunchKernelGGL(sum_pass2, dim3(1), dim3(kBlock), 0, s, ws2, kSumBlocks, scale, out);
     }
+    return launch_status();
+}
+
+int sph2pob_loss_fwd_grad_f32(const float* pred, const float* target, const float* weight, int weight_dim, float scale,
+                              float* loss, float* out_sum, float* workspace, float* grad_pred, float* grad_target,
+                              int64_t n, int box_dim, int loss_mode_flags, float eps, void* stream) {
+    const int loss_mode = loss_mode_flags & 0xff;
+    const bool fast = !(loss_mode_flags & SPH2POB_FLAG_REFERENCE_ORDER);
+    if (loss_mode_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER)) return SPH2POB_ERR_OPTION;
+    if (box_dim != 4 && box_dim != 5) return SPH2POB_ERR_DIM;
+    if (loss_mode < 0 || loss_mode > 3) return SPH2POB_ERR_OPTION;
+    if (weight && weight_dim != 1 && weight_dim != box_dim) return SPH2POB_ERR_OPTION;
+    if (n < 0 || n > kMaxElems) return SPH2POB_ERR_SIZE;
+    if ((out_sum && !workspace) || (n > 0 && (!pred || !target || !grad_pred))) return SPH2POB_ERR_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nb = (n + kBlock - 1) / kBlock;
+    float* partial = out_sum ? workspace : nullptr;
+    if (nb > 0) {
+        dim3 grid((unsigned)nb);
+#define SPH_LOSS_FG(D, F) \
+        hipLaunchKernelGGL((loss_fwd_grad_kernel<D, F>), grid, dim3(kBlock), 0, s, pred, target, weight, weight_dim, scale, loss, partial, grad_pred, grad_target, n, loss_mode, eps)
+        if (box_dim == 4) { if (fast) SPH_LOSS_FG(4, true); else SPH_LOSS_FG(4, false); }
+        else { if (fast) SPH_LOSS_FG(5, true); else SPH_LOSS_FG(5, false); }
+#undef SPH_LOSS_FG
+    }
+    if (out_sum) {   // scale is already inside the elements
+        if (nb <= 65536) {
+            hipLaunchKernelGGL(sum_pass2, dim3(1), dim3(kBlock), 0, s, workspace, (int)nb, 1.0f, out_sum);
+        } else {
+            float* ws2 = workspace + nb;
+            hipLaunchKernelGGL(sum_pass1, dim3(kSumBlocks), dim3(kBlock), 0, s, workspace, nb, ws2);
+            hipLaunchKernelGGL(sum_pass2, dim3(1), dim3(kBlock), 0, s, ws2, kSumBlocks, 1.0f, out_sum);
+        }
+    }
+    return launch_status();
+}
+
+int sph2pob_loss_grad_scale_f32(const float* stash, const float* grad_out, int grad_stride, float* out, int64_t n,
+                                int box_dim, void* stream) {
+    if (box_dim != 4 && box_dim != 5) return SPH2POB_ERR_DIM;
+    if (grad_stride != 0 && grad_stride != 1) return SPH2POB_ERR_OPTION;
+    if (n < 0 || n > kMaxElems) return SPH2POB_ERR_SIZE;
+    if (n == 0) return SPH2POB_OK;
+    if (!stash || !grad_out || !out) return SPH2POB_ERR_NULL;
+    const int64_t total = n * box_dim;
+    hipLaunchKernelGGL(grad_scale_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                       stash, grad_out, grad_stride, out, total, box_dim);
     return launch_status();
 }
 

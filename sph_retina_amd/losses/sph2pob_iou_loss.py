@@ -34,8 +34,11 @@ def _f32c(t):
 class _Sph2PobLossFunction(torch.autograd.Function):
     """(pred, target[, weight]) -> scale * weighted element losses (reduce=False) or scale * their sum (reduce=True).
     One node in the autograd graph: `scale` carries loss_weight AND the 1 / n | 1 / (avg_factor + eps) of
-    weight_reduce_loss, so 'mean' costs no extra torch op (and no extra backward node) on top of the two forward launches
-    (loss + per-workgroup partial sums, final sum) and the one backward launch."""
+    weight_reduce_loss, so 'mean' costs no extra torch op (and no extra backward node).
+    When a gradient will be asked for (pred or target requires grad) the forward launch is the fused one
+    (`sph2pob_loss_fwd_grad_f32`): the backward kernel has to recompute the whole forward anyway, so loss and gradients for
+    an upstream gradient of 1 come out of ONE pass over the boxes and torch's backward only scales the stashed gradients
+    (`sph2pob_loss_grad_scale_f32`).  Without a gradient in sight (evaluation) the plain forward kernels run."""
 
     @staticmethod
     def forward(ctx, pred, target, weight, mode_c, eps, scale, reduce):
@@ -47,37 +50,44 @@ class _Sph2PobLossFunction(torch.autograd.Function):
         wp = w.data_ptr() if w is not None and n else None
         dev = p.device
         stream = G.raw_stream_of(dev)
-        if reduce:
-            out = torch.empty((), dtype=torch.float32, device=dev)
+        need_p, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        out = torch.empty(() if reduce else (n,), dtype=torch.float32, device=dev)
+        if need_p or need_t:
+            gp = torch.empty_like(p)
+            gt = torch.empty_like(t) if need_t else None
+            ws = G.loss_sum_workspace(dev, n) if reduce else None
+            G.call('sph2pob_loss_fwd_grad_f32', dev, p.data_ptr() if n else None, t.data_ptr() if n else None, wp, wd, scale,
+                   None if reduce else (out.data_ptr() if n else None), out.data_ptr() if reduce else None,
+                   ws.data_ptr() if reduce else None, gp.data_ptr() if n else None, gt.data_ptr() if need_t and n else None,
+                   n, dim, mode_c, eps, stream)
+            ctx.save_for_backward(gp, gt)
+        elif reduce:
             G.call('sph2pob_loss_fwd_sum_f32', dev, p.data_ptr() if n else None, t.data_ptr() if n else None, wp, wd, scale,
                    out.data_ptr(), G.loss_sum_workspace(dev, n).data_ptr(), n, dim, mode_c, eps, stream)
-        else:
-            out = torch.empty((n,), dtype=torch.float32, device=dev)
-            if n:
-                G.call('sph2pob_loss_fwd_f32', dev, p.data_ptr(), t.data_ptr(), wp, wd, scale, out.data_ptr(), None, n, dim,
-                       mode_c, eps, stream)
-        ctx.save_for_backward(p, t, w)
-        ctx.meta = (mode_c, eps, scale, reduce, wd, pred.dtype, target.dtype)
+        elif n:
+            G.call('sph2pob_loss_fwd_f32', dev, p.data_ptr(), t.data_ptr(), wp, wd, scale, out.data_ptr(), None, n, dim,
+                   mode_c, eps, stream)
+        ctx.meta = (reduce, need_p, need_t, pred.dtype, target.dtype)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        p, t, w = ctx.saved_tensors
-        mode_c, eps, scale, reduce, wd, pdt, tdt = ctx.meta
-        n, dim = p.shape
-        need_p, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gp, gt = ctx.saved_tensors
+        reduce, need_p, need_t, pdt, tdt = ctx.meta
+        n, dim = gp.shape
         g = _f32c(grad_out)
-        gp = torch.empty_like(p)
-        gt = torch.empty_like(t) if need_t else None
-        if n:
-            G.call('sph2pob_loss_bwd_f32', p.device, p.data_ptr(), t.data_ptr(), w.data_ptr() if w is not None else None, wd,
-                   g.data_ptr(), 0 if reduce else 1, scale, gp.data_ptr(), gt.data_ptr() if need_t else None, n, dim, mode_c,
-                   eps, G.raw_stream_of(p.device))
-        if pdt is not torch.float32:
-            gp = gp.to(pdt)
-        if need_t and tdt is not torch.float32:
-            gt = gt.to(tdt)
-        return (gp if need_p else None), (gt if need_t else None), None, None, None, None, None
+        stream = G.raw_stream_of(gp.device)
+        outs = []
+        for stash, need, dt in ((gp, need_p, pdt), (gt, need_t, tdt)):
+            if not need or stash is None:
+                outs.append(None)
+                continue
+            o = torch.empty_like(stash)
+            if n:
+                G.call('sph2pob_loss_grad_scale_f32', stash.device, stash.data_ptr(), g.data_ptr(), 0 if reduce else 1,
+                       o.data_ptr(), n, dim, stream)
+            outs.append(o if dt is torch.float32 else o.to(dt))
+        return outs[0], outs[1], None, None, None, None, None
 
 
 def sph2pob_iou_loss(pred, target, weight=None, mode='iou', eps=1e-6, reduction='mean', avg_factor=None,

@@ -285,3 +285,48 @@ def test_mmrotate_loss_bodies_are_wrapped_when_mmrotate_is_present(L, monkeypatc
     finally:
         monkeypatch.undo()
         importlib.reload(M)
+
+
+@pytest.mark.parametrize('box', ['bfov', 'rbfov'])
+@pytest.mark.parametrize('weighted', [False, True])
+def test_c_abi_one_pass_and_two_pass_forms_agree(L, box, weighted):
+    """The C ABI offers the training step in two forms: `sph2pob_loss_fwd_grad_f32` (loss + gradients in one pass, then
+    `sph2pob_loss_grad_scale_f32`) — what the autograd Function launches — and the round-1 form `sph2pob_loss_fwd_sum_f32` /
+    `sph2pob_loss_fwd_f32` + `sph2pob_loss_bwd_f32` (a backward kernel that recomputes the forward).  Same arithmetic:
+    losses and gradients must be identical bit for bit, also for a non-unit upstream gradient, weights and 'none'."""
+    from sph_retina_amd import _lib
+    lib = _lib.lib()
+    g = load_golden('loss_' + box)
+    p, t = cu(g['pred']), cu(g['target'])
+    n, dim = p.shape
+    w = (torch.rand(n, device='cuda') > 0.3).float() * torch.rand(n, device='cuda') if weighted else None
+    wp, wd = (w.data_ptr(), 1) if weighted else (None, 0)
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(int(lib.sph2pob_loss_sum_workspace_floats(n)), device='cuda')
+    for mode in range(4):
+        s1, s2 = torch.empty((), device='cuda'), torch.empty((), device='cuda')
+        e1, e2 = torch.empty(n, device='cuda'), torch.empty(n, device='cuda')
+        gp1, gt1, gp2, gt2 = (torch.empty_like(p) for _ in range(4))
+        assert lib.sph2pob_loss_fwd_grad_f32(p.data_ptr(), t.data_ptr(), wp, wd, 0.25, e1.data_ptr(), s1.data_ptr(), ws.data_ptr(),
+                                             gp1.data_ptr(), gt1.data_ptr(), n, dim, mode, 1e-6, st) == 0
+        assert lib.sph2pob_loss_fwd_f32(p.data_ptr(), t.data_ptr(), wp, wd, 0.25, e2.data_ptr(), None, n, dim, mode, 1e-6, st) == 0
+        assert lib.sph2pob_loss_fwd_sum_f32(p.data_ptr(), t.data_ptr(), wp, wd, 0.25, s2.data_ptr(), ws.data_ptr(), n, dim, mode,
+                                            1e-6, st) == 0
+        assert torch.equal(e1, e2) and torch.equal(s1, s2)
+        assert abs(float(s1) - float(e1.double().sum())) < 1e-4 * max(1.0, abs(float(s1)))
+        # scalar upstream gradient (reduced loss)
+        up = torch.full((), 0.7, device='cuda')
+        o1, o2 = torch.empty_like(p), torch.empty_like(p)
+        assert lib.sph2pob_loss_grad_scale_f32(gp1.data_ptr(), up.data_ptr(), 0, o1.data_ptr(), n, dim, st) == 0
+        assert lib.sph2pob_loss_bwd_f32(p.data_ptr(), t.data_ptr(), wp, wd, up.data_ptr(), 0, 0.25, gp2.data_ptr(), gt2.data_ptr(),
+                                        n, dim, mode, 1e-6, st) == 0
+        assert torch.allclose(o1, gp2, rtol=2e-7, atol=0) and torch.equal(o1 == 0, gp2 == 0)   # (w g) x vs (g w) x: one rounding
+        # per-element upstream gradients (reduction 'none')
+        ue = torch.rand(n, device='cuda')
+        assert lib.sph2pob_loss_grad_scale_f32(gt1.data_ptr(), ue.data_ptr(), 1, o1.data_ptr(), n, dim, st) == 0
+        assert lib.sph2pob_loss_bwd_f32(p.data_ptr(), t.data_ptr(), wp, wd, ue.data_ptr(), 1, 0.25, gp2.data_ptr(), gt2.data_ptr(),
+                                        n, dim, mode, 1e-6, st) == 0
+        assert torch.allclose(o1, gt2, rtol=2e-7, atol=0)
+    # argument validation
+    assert lib.sph2pob_loss_fwd_grad_f32(p.data_ptr(), t.data_ptr(), None, 0, 1.0, None, None, None, None, None, n, dim, 0, 1e-6, st) == -1
+    assert lib.sph2pob_loss_grad_scale_f32(gp1.data_ptr(), up.data_ptr(), 2, o1.data_ptr(), n, dim, st) == -3
