@@ -343,8 +343,43 @@ def l1_only():
     save('l1', **arrs)
 
 
+def transform_bwd_only():
+    """Gradients of the transforms that have no closed-form backward in the kernels — sph2pob_legacy and
+    rbb_angle='project' of sph2pob_standard / sph2pob_efficient — from the reference's own torch autograd
+    (sphdet/iou/sph2pob_legacy.py:8-31, sph2pob_standard.py:8-80, sph2pob_efficient.py:9-73), float32 and float64."""
+    torch.manual_seed(20261004)
+    arrs = {}
+    cases = [('legacy', R.leg.sph2pob_legacy, 'bfov', {}), ('standard_project', R.std.sph2pob_standard, 'bfov', dict(rbb_angle='project')),
+             ('standard_project', R.std.sph2pob_standard, 'rbfov', dict(rbb_angle='project')),
+             ('efficient_project', R.eff.sph2pob_efficient, 'bfov', dict(rbb_angle='project')),
+             ('efficient_project', R.eff.sph2pob_efficient, 'rbfov', dict(rbb_angle='project'))]
+    for name, fn, box, kw in cases:
+        for near in (False, True):
+            g, p = gen(300, box=box, near=near)
+            go1, go2 = torch.randn(300, 5), torch.randn(300, 5)
+            for edge in ('arc', 'chord'):
+                key = f'{name}_{box}_{"near" if near else "uni"}_{edge}_'
+
+                def run(gg, pp, o1, o2):
+                    a, b = gg.clone().requires_grad_(True), pp.clone().requires_grad_(True)
+                    q1, q2 = fn(a.clone(), b.clone(), rbb_angle_version='rad', rbb_edge=edge, **kw)   # the reference mutates its inputs (legacy :254): clones, as sph2pob_transform.py:26-27 passes
+                    ((q1 * o1).sum() + (q2 * o2).sum()).backward()
+                    return q1.detach(), q2.detach(), a.grad, b.grad
+                q1, q2, ga, gb = run(g, p, go1, go2)
+                torch.set_default_dtype(torch.float64)
+                try:
+                    _, _, ga64, gb64 = run(g.double(), p.double(), go1.double(), go2.double())
+                finally:
+                    torch.set_default_dtype(torch.float32)
+                arrs.update({key + 'b1': g, key + 'b2': p, key + 'go1': go1, key + 'go2': go2, key + 'p1': q1, key + 'p2': q2,
+                             key + 'g1': ga, key + 'g2': gb, key + 'g1_64': ga64, key + 'g2_64': gb64})
+    save('transform_bwd', **arrs)
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'samples_backends':
+    if len(sys.argv) > 1 and sys.argv[1] == 'transform_bwd':
+        transform_bwd_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'samples_backends':
         samples_backends_only()
     elif len(sys.argv) > 1 and sys.argv[1] == 'l1':
         l1_only()
@@ -361,3 +396,4 @@ if __name__ == '__main__':
         unbiased_only()
         l1_only()
         samples_backends_only()
+        transform_bwd_only()

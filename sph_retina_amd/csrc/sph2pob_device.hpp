@@ -27,8 +27,15 @@ enum : int { MODE_IOU = 0, MODE_IOF = 1 };
 enum : int { EDGE_ARC = 0, EDGE_CHORD = 1, EDGE_TANGENT = 2 };
 enum : int { ANGLE_EQUATOR = 0, ANGLE_PROJECT = 1 };
 
-struct PBox { float x, y, w, h, a; };
-struct V3 { float x, y, z; };
+// The reference-order transforms below are written once for a scalar type T: float — the kernels' arithmetic, the
+// reference's own fp32 operation order — and Dual, a forward-mode (value, derivative) pair used ONLY by the adjoint of
+// the transforms that have no closed-form backward here (sph2pob_legacy, rbb_angle='project': transform_bwd_dual_kernel).
+// With T = float every helper is the plain libm / builtin call it replaces: same instructions, same bits.
+struct Dual { float v, d; };
+template <class T> struct PBoxT { T x, y, w, h, a; };
+template <class T> struct V3T { T x, y, z; };
+using PBox = PBoxT<float>;
+using V3 = V3T<float>;
 
 #define SPH_DEV __host__ __device__ __forceinline__
 
@@ -64,30 +71,68 @@ SPH_DEV bool pair_has_nan(const float (&a)[5], const float (&b)[5]) {
     return m != m;
 }
 
-SPH_DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
-SPH_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
-SPH_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
-SPH_DEV float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-SPH_DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+// ---- Dual arithmetic (torch autograd's rules: clamp / max pass the gradient on the closed side, |x| uses sign) ----
+SPH_DEV float val(float x) { return x; }
+SPH_DEV float val(Dual x) { return x.v; }
+SPH_DEV Dual operator+(Dual a, Dual b) { return Dual{a.v + b.v, a.d + b.d}; }
+SPH_DEV Dual operator-(Dual a, Dual b) { return Dual{a.v - b.v, a.d - b.d}; }
+SPH_DEV Dual operator-(Dual a) { return Dual{-a.v, -a.d}; }
+SPH_DEV Dual operator*(Dual a, Dual b) { return Dual{a.v * b.v, a.d * b.v + a.v * b.d}; }
+SPH_DEV Dual operator/(Dual a, Dual b) { const float q = a.v / b.v; return Dual{q, (a.d - q * b.d) / b.v}; }
+SPH_DEV Dual operator+(Dual a, float b) { return Dual{a.v + b, a.d}; }
+SPH_DEV Dual operator+(float a, Dual b) { return Dual{a + b.v, b.d}; }
+SPH_DEV Dual operator-(Dual a, float b) { return Dual{a.v - b, a.d}; }
+SPH_DEV Dual operator-(float a, Dual b) { return Dual{a - b.v, -b.d}; }
+SPH_DEV Dual operator*(Dual a, float b) { return Dual{a.v * b, a.d * b}; }
+SPH_DEV Dual operator*(float a, Dual b) { return Dual{a * b.v, a * b.d}; }
+SPH_DEV Dual operator/(Dual a, float b) { return Dual{a.v / b, a.d / b}; }
+SPH_DEV float m_sin(float x) { return sinf(x); }
+SPH_DEV float m_cos(float x) { return cosf(x); }
+SPH_DEV float m_tan(float x) { return tanf(x); }
+SPH_DEV float m_acos(float x) { return acosf(x); }
+SPH_DEV float m_asin(float x) { return asinf(x); }
+SPH_DEV float m_sqrt(float x) { return sqrtf(x); }
+SPH_DEV float m_abs(float x) { return fabsf(x); }
+SPH_DEV float m_max(float x, float lo) { return fmaxf(x, lo); }
+SPH_DEV float m_clamp(float x, float lo, float hi) { return clampf(x, lo, hi); }
+SPH_DEV float m_fmod(float x, float m) { return fmodf(x, m); }
+SPH_DEV Dual m_sin(Dual x) { return Dual{sinf(x.v), cosf(x.v) * x.d}; }
+SPH_DEV Dual m_cos(Dual x) { return Dual{cosf(x.v), -sinf(x.v) * x.d}; }
+SPH_DEV Dual m_tan(Dual x) { const float t = tanf(x.v); return Dual{t, (1.0f + t * t) * x.d}; }
+SPH_DEV Dual m_acos(Dual x) { return Dual{acosf(x.v), -x.d / sqrtf(1.0f - x.v * x.v)}; }
+SPH_DEV Dual m_asin(Dual x) { return Dual{asinf(x.v), x.d / sqrtf(1.0f - x.v * x.v)}; }
+SPH_DEV Dual m_sqrt(Dual x) { const float r = sqrtf(x.v); return Dual{r, 0.5f * x.d / r}; }
+SPH_DEV Dual m_abs(Dual x) { return Dual{fabsf(x.v), x.v > 0.0f ? x.d : (x.v < 0.0f ? -x.d : 0.0f)}; }
+SPH_DEV Dual m_max(Dual x, float lo) { return Dual{fmaxf(x.v, lo), x.v >= lo ? x.d : 0.0f}; }
+SPH_DEV Dual m_clamp(Dual x, float lo, float hi) { return Dual{clampf(x.v, lo, hi), (x.v >= lo && x.v <= hi) ? x.d : 0.0f}; }
+SPH_DEV Dual m_fmod(Dual x, float m) { return Dual{fmodf(x.v, m), x.d}; }
+
+template <class T> SPH_DEV V3T<T> v3(T x, T y, T z) { return V3T<T>{x, y, z}; }
+template <class T> SPH_DEV V3T<T> operator+(V3T<T> a, V3T<T> b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <class T> SPH_DEV V3T<T> operator-(V3T<T> a, V3T<T> b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <class T> SPH_DEV T dot(V3T<T> a, V3T<T> b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+template <class T> SPH_DEV V3T<T> cross(V3T<T> a, V3T<T> b) {
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
 // F.normalize: v / max(||v||, 1e-12)
-SPH_DEV V3 normalize(V3 a) {
-    float n = sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z);
-    float d = fmaxf(n, 1e-12f);
+template <class T> SPH_DEV V3T<T> normalize(V3T<T> a) {
+    T n = m_sqrt((a.x * a.x + a.y * a.y) + a.z * a.z);
+    T d = m_max(n, 1e-12f);
     return v3(a.x / d, a.y / d, a.z / d);
 }
 // compute_angle_between_direction (radians): sph2pob_efficient.py:192-208
-SPH_DEV float angle_between(V3 a, V3 b) {
-    float c = clampf(dot(normalize(a), normalize(b)), kClampLo, kClampHi);
-    return fabsf(acosf(c));
+template <class T> SPH_DEV T angle_between(V3T<T> a, V3T<T> b) {
+    T c = m_clamp(dot(normalize(a), normalize(b)), kClampLo, kClampHi);
+    return m_abs(m_acos(c));
 }
-SPH_DEV float rad2deg_ref(float r) { return r / kPi * 180.0f; }  // sph2pob_standard.py:216
+template <class T> SPH_DEV T rad2deg_ref(T r) { return r / kPi * 180.0f; }  // sph2pob_standard.py:216
 // compute_clockwise_or_anticlockwise_between_direction: sph2pob_efficient.py:211-226
-SPH_DEV float sign_mask(V3 a, V3 b, V3 ref) { return dot(cross(a, b), ref) < 0.0f ? 1.0f : -1.0f; }
+template <class T> SPH_DEV float sign_mask(V3T<T> a, V3T<T> b, V3T<T> ref) { return val(dot(cross(a, b), ref)) < 0.0f ? 1.0f : -1.0f; }
 
-SPH_DEV float edge_length(float fov, int edge) {  // sph2pob_standard.py:110-118
+template <class T> SPH_DEV T edge_length(T fov, int edge) {  // sph2pob_standard.py:110-118
     if (edge == EDGE_ARC) return fov;
-    if (edge == EDGE_TANGENT) return 2.0f * tanf(fov / 2.0f);
-    return 2.0f * sinf(fov / 2.0f);
+    if (edge == EDGE_TANGENT) return 2.0f * m_tan(fov / 2.0f);
+    return 2.0f * m_sin(fov / 2.0f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -139,78 +184,81 @@ SPH_DEV void jitter_rotated(PBox& p1, PBox& p2) {
 }
 
 // ------------------------------------------------------------------------------------------------
-struct SBox { float th, ph, al, be, ga, st, ct, sp, cp; V3 c, d; };
+template <class T> struct SBoxT { T th, ph, al, be, ga, st, ct, sp, cp; V3T<T> c, d; };
+using SBox = SBoxT<float>;
 
-template <int DIM>
-SPH_DEV SBox load_sbox(const float (&b)[5]) {  // sph2pob_standard.py:23-41, 121-172
-    SBox s;
+template <int DIM, class T>
+SPH_DEV SBoxT<T> load_sbox(const T (&b)[5]) {  // sph2pob_standard.py:23-41, 121-172
+    SBoxT<T> s;
     s.th = b[0] * kDeg2Rad; s.ph = b[1] * kDeg2Rad; s.al = b[2] * kDeg2Rad; s.be = b[3] * kDeg2Rad;
-    s.ga = DIM == 5 ? b[4] * kDeg2Rad : 0.0f;
-    s.st = sinf(s.th); s.ct = cosf(s.th); s.sp = sinf(s.ph); s.cp = cosf(s.ph);
+    s.ga = DIM == 5 ? b[4] * kDeg2Rad : b[4] * 0.0f;
+    s.st = m_sin(s.th); s.ct = m_cos(s.th); s.sp = m_sin(s.ph); s.cp = m_cos(s.ph);
     s.c = v3(s.sp * s.ct, s.sp * s.st, s.cp);
     s.d = v3(s.cp * s.ct, s.cp * s.st, -s.sp);
     return s;
 }
 
-struct M3 { V3 r0, r1, r2; };
-SPH_DEV V3 mul(const M3& m, V3 v) { return v3(dot(m.r0, v), dot(m.r1, v), dot(m.r2, v)); }
+template <class T> struct M3T { V3T<T> r0, r1, r2; };
+using M3 = M3T<float>;
+template <class T> SPH_DEV V3T<T> mul(const M3T<T>& m, V3T<T> v) { return v3(dot(m.r0, v), dot(m.r1, v), dot(m.r2, v)); }
 // compute_rotate_matrix(theta, phi): rows look, down, right — sph2pob_standard.py:239-261
-SPH_DEV M3 rotate_matrix(float st, float ct, float sp, float cp) {
-    return M3{v3(sp * ct, sp * st, cp), v3(cp * ct, cp * st, -sp), v3(st, -ct, 0.0f)};
+template <class T> SPH_DEV M3T<T> rotate_matrix(T st, T ct, T sp, T cp) {
+    return M3T<T>{v3(sp * ct, sp * st, cp), v3(cp * ct, cp * st, -sp), v3(st, -ct, ct * 0.0f)};
 }
 // dir <- T^T (Rx(gamma) T) dir — compute_gamma_matrix, sph2pob_standard.py:300-314 (matrix products kept)
-SPH_DEV V3 apply_gamma(const SBox& s, float gamma, V3 dir) {
-    M3 T = rotate_matrix(s.st, s.ct, s.sp, s.cp);
-    float sg = sinf(gamma), cg = cosf(gamma);
+template <class T> SPH_DEV V3T<T> apply_gamma(const SBoxT<T>& s, T gamma, V3T<T> dir) {
+    M3T<T> Tm = rotate_matrix(s.st, s.ct, s.sp, s.cp);
+    T sg = m_sin(gamma), cg = m_cos(gamma);
     // RT = Rx * T  (rows)
-    M3 RT;
-    RT.r0 = T.r0;
-    RT.r1 = v3((0.0f * T.r0.x + cg * T.r1.x) + (-sg) * T.r2.x, (0.0f * T.r0.y + cg * T.r1.y) + (-sg) * T.r2.y,
-               (0.0f * T.r0.z + cg * T.r1.z) + (-sg) * T.r2.z);
-    RT.r2 = v3((0.0f * T.r0.x + sg * T.r1.x) + cg * T.r2.x, (0.0f * T.r0.y + sg * T.r1.y) + cg * T.r2.y,
-               (0.0f * T.r0.z + sg * T.r1.z) + cg * T.r2.z);
+    M3T<T> RT;
+    RT.r0 = Tm.r0;
+    RT.r1 = v3((0.0f * Tm.r0.x + cg * Tm.r1.x) + (-sg) * Tm.r2.x, (0.0f * Tm.r0.y + cg * Tm.r1.y) + (-sg) * Tm.r2.y,
+               (0.0f * Tm.r0.z + cg * Tm.r1.z) + (-sg) * Tm.r2.z);
+    RT.r2 = v3((0.0f * Tm.r0.x + sg * Tm.r1.x) + cg * Tm.r2.x, (0.0f * Tm.r0.y + sg * Tm.r1.y) + cg * Tm.r2.y,
+               (0.0f * Tm.r0.z + sg * Tm.r1.z) + cg * Tm.r2.z);
     // G = T^T * RT : G[i][j] = sum_k T[k][i] * RT[k][j]
-    V3 c0 = v3(T.r0.x, T.r1.x, T.r2.x), c1 = v3(T.r0.y, T.r1.y, T.r2.y), c2 = v3(T.r0.z, T.r1.z, T.r2.z);
-    V3 q0 = v3(RT.r0.x, RT.r1.x, RT.r2.x), q1 = v3(RT.r0.y, RT.r1.y, RT.r2.y), q2 = v3(RT.r0.z, RT.r1.z, RT.r2.z);
-    M3 G{v3(dot(c0, q0), dot(c0, q1), dot(c0, q2)), v3(dot(c1, q0), dot(c1, q1), dot(c1, q2)),
-         v3(dot(c2, q0), dot(c2, q1), dot(c2, q2))};
-    return mul(G, dir);
+    V3T<T> c0 = v3(Tm.r0.x, Tm.r1.x, Tm.r2.x), c1 = v3(Tm.r0.y, Tm.r1.y, Tm.r2.y), c2 = v3(Tm.r0.z, Tm.r1.z, Tm.r2.z);
+    V3T<T> q0 = v3(RT.r0.x, RT.r1.x, RT.r2.x), q1 = v3(RT.r0.y, RT.r1.y, RT.r2.y), q2 = v3(RT.r0.z, RT.r1.z, RT.r2.z);
+    M3T<T> Gm{v3(dot(c0, q0), dot(c0, q1), dot(c0, q2)), v3(dot(c1, q0), dot(c1, q1), dot(c1, q2)),
+              v3(dot(c2, q0), dot(c2, q1), dot(c2, q2))};
+    return mul(Gm, dir);
 }
 
-template <int DIM>
-SPH_DEV void transform_standard(const float (&g_)[5], const float (&p_)[5], int edge, int angle, PBox& og, PBox& op) {
-    SBox g = load_sbox<DIM>(g_), p = load_sbox<DIM>(p_);
-    M3 R;
-    V3 df = g.c - p.c;
-    float l1 = (fabsf(df.x) + fabsf(df.y)) + fabsf(df.z);
+template <int DIM, class T>
+SPH_DEV void transform_standard(const T (&g_)[5], const T (&p_)[5], int edge, int angle, PBoxT<T>& og, PBoxT<T>& op) {
+    SBoxT<T> g = load_sbox<DIM>(g_), p = load_sbox<DIM>(p_);
+    M3T<T> R;
+    V3T<T> df = g.c - p.c;
+    float l1 = (fabsf(val(df.x)) + fabsf(val(df.y))) + fabsf(val(df.z));
     if (l1 > 1e-8f) {  // compute_rotate_matrix_better :264-283
-        V3 look = normalize(g.c + p.c);
-        V3 right = normalize(p.c - g.c);
-        R = M3{look, right, cross(look, right)};
+        V3T<T> look = normalize(g.c + p.c);
+        V3T<T> right = normalize(p.c - g.c);
+        R = M3T<T>{look, right, cross(look, right)};
     } else {  // compute_rotate_matrix(theta_r, phi_r) :286-297
-        float th_r = (g.th + p.th) / 2.0f, ph_r = (g.ph + p.ph) / 2.0f;
-        R = rotate_matrix(sinf(th_r), cosf(th_r), sinf(ph_r), cosf(ph_r));
+        T th_r = (g.th + p.th) / 2.0f, ph_r = (g.ph + p.ph) / 2.0f;
+        R = rotate_matrix(m_sin(th_r), m_cos(th_r), m_sin(ph_r), m_cos(ph_r));
     }
-    V3 dg = g.d, dp = p.d;
+    V3T<T> dg = g.d, dp = p.d;
     if (DIM == 5) {
         dg = apply_gamma(g, -g.ga, dg);
         dp = apply_gamma(p, -p.ga, dp);
     }
-    V3 cg = mul(R, g.c), cp = mul(R, p.c);
+    V3T<T> cg = mul(R, g.c), cp = mul(R, p.c);
     dg = mul(R, dg);
     dp = mul(R, dp);
-    const V3 ez = v3(0.0f, 0.0f, 1.0f), ex = v3(1.0f, 0.0f, 0.0f);
-    auto internal_angle = [&](V3 d) {  // compute_internal_angle :88-108 (+ deg2rad of standardize_rotated_box)
-        if (angle == ANGLE_PROJECT) d.x = 0.0f;
-        float a = fabsf(rad2deg_ref(angle_between(d, ez)));
-        a = a * (d.y > 0.0f ? 1.0f : -1.0f);  // sign_mask(ez, d, ex) == (-d.y < 0)
+    const T zero = g.th * 0.0f, one = zero + 1.0f;   // constants of the scalar type (derivative 0)
+    const V3T<T> ez = v3(zero, zero, one), ex = v3(one, zero, zero);
+    auto internal_angle = [&](V3T<T> d) {  // compute_internal_angle :88-108 (+ deg2rad of standardize_rotated_box)
+        if (angle == ANGLE_PROJECT) d.x = zero;
+        T a = m_abs(rad2deg_ref(angle_between(d, ez)));
+        a = a * (val(d.y) > 0.0f ? 1.0f : -1.0f);  // sign_mask(ez, d, ex) == (-d.y < 0)
         return a * kDeg2Rad;
     };
-    auto sph_coord = [&](V3 c, float& th, float& ph) {  // compute_spherical_coordinate :175-199
+    auto sph_coord = [&](V3T<T> c, T& th, T& ph) {  // compute_spherical_coordinate :175-199
         ph = rad2deg_ref(angle_between(c, ez)) * kDeg2Rad;
-        V3 cxy = v3(c.x, c.y, 0.0f);
-        float t = rad2deg_ref(angle_between(cxy, ex));
-        t = t * (c.y > 0.0f ? 1.0f : -1.0f);  // sign_mask(ex, cxy, -ez) == (-c.y < 0)
+        V3T<T> cxy = v3(c.x, c.y, zero);
+        T t = rad2deg_ref(angle_between(cxy, ex));
+        t = t * (val(c.y) > 0.0f ? 1.0f : -1.0f);  // sign_mask(ex, cxy, -ez) == (-c.y < 0)
         th = t * kDeg2Rad;
     };
     og.a = internal_angle(dg);
@@ -221,52 +269,55 @@ SPH_DEV void transform_standard(const float (&g_)[5], const float (&p_)[5], int 
     op.w = edge_length(p.al, edge); op.h = edge_length(p.be, edge);
 }
 
-template <int DIM>
-SPH_DEV void transform_efficient(const float (&g_)[5], const float (&p_)[5], int edge, int angle, PBox& og, PBox& op) {
-    SBox g = load_sbox<DIM>(g_), p = load_sbox<DIM>(p_);
-    V3 z = cross(g.c, p.c);
-    V3 s = g.c + p.c;
-    V3 ref = v3(s.x / 2.0f, s.y / 2.0f, s.z / 2.0f);
-    float arc = angle_between(g.c, p.c);
-    V3 dg = g.d, dp = p.d;
-    if (angle == ANGLE_PROJECT) { dg.x = 0.0f; dp.x = 0.0f; }  // :92-93, unrotated-frame quirk kept
-    float ag = angle_between(dg, z) * sign_mask(z, dg, ref);
-    float ap = angle_between(dp, z) * sign_mask(z, dp, ref);
+template <int DIM, class T>
+SPH_DEV void transform_efficient(const T (&g_)[5], const T (&p_)[5], int edge, int angle, PBoxT<T>& og, PBoxT<T>& op) {
+    SBoxT<T> g = load_sbox<DIM>(g_), p = load_sbox<DIM>(p_);
+    V3T<T> z = cross(g.c, p.c);
+    V3T<T> s = g.c + p.c;
+    V3T<T> ref = v3(s.x / 2.0f, s.y / 2.0f, s.z / 2.0f);
+    T arc = angle_between(g.c, p.c);
+    V3T<T> dg = g.d, dp = p.d;
+    const T zero = g.th * 0.0f;
+    if (angle == ANGLE_PROJECT) { dg.x = zero; dp.x = zero; }  // :92-93, unrotated-frame quirk kept
+    T ag = angle_between(dg, z) * sign_mask(z, dg, ref);
+    T ap = angle_between(dp, z) * sign_mask(z, dp, ref);
     if (DIM == 5) { ag = ag - g.ga; ap = ap - p.ga; }
-    og = PBox{0.0f, 0.0f, edge_length(g.al, edge), edge_length(g.be, edge), ag};
-    op = PBox{arc, 0.0f, edge_length(p.al, edge), edge_length(p.be, edge), ap};
+    og = PBoxT<T>{zero, zero, edge_length(g.al, edge), edge_length(g.be, edge), ag};
+    op = PBoxT<T>{arc, zero, edge_length(p.al, edge), edge_length(p.be, edge), ap};
 }
 
-SPH_DEV float legacy_angle_aux(float th_box, float ph_box, float th_ref, float ph_ref) {  // sph2pob_legacy.py:120-134
-    float sb = sinf(th_box), cb = cosf(th_box), spb = sinf(ph_box), cpb = cosf(ph_box);
-    float sr = sinf(th_ref), cr = cosf(th_ref), spr = sinf(ph_ref), cpr = cosf(ph_ref);
-    V3 db = v3(cpb * cb, cpb * sb, -spb), dr = v3(cpr * cr, cpr * sr, -spr);
-    float a = fabsf(rad2deg_ref(angle_between(db, dr)));
+template <class T>
+SPH_DEV T legacy_angle_aux(T th_box, T ph_box, T th_ref, T ph_ref) {  // sph2pob_legacy.py:120-134
+    T sb = m_sin(th_box), cb = m_cos(th_box), spb = m_sin(ph_box), cpb = m_cos(ph_box);
+    T sr = m_sin(th_ref), cr = m_cos(th_ref), spr = m_sin(ph_ref), cpr = m_cos(ph_ref);
+    V3T<T> db = v3(cpb * cb, cpb * sb, -spb), dr = v3(cpr * cr, cpr * sr, -spr);
+    T a = m_abs(rad2deg_ref(angle_between(db, dr)));
     const float hp = (float)(3.141592653589793 / 2);
-    bool sign = ((th_box >= th_ref) && (ph_box < hp)) || ((th_box <= th_ref) && (ph_box > hp));
+    bool sign = ((val(th_box) >= val(th_ref)) && (val(ph_box) < hp)) || ((val(th_box) <= val(th_ref)) && (val(ph_box) > hp));
     return sign ? a : a * -1.0f;
 }
-SPH_DEV void transform_legacy(const float (&g_)[5], const float (&p_)[5], int edge, PBox& og, PBox& op) {
-    float g0 = g_[0], p0 = p_[0];
-    if (fabsf(g0 - p0) > 180.0f) {  // standardize_spherical_box :236-257
-        g0 = fmodf(g0 + 180.0f, 360.0f);
-        p0 = fmodf(p0 + 180.0f, 360.0f);
+template <class T>
+SPH_DEV void transform_legacy(const T (&g_)[5], const T (&p_)[5], int edge, PBoxT<T>& og, PBoxT<T>& op) {
+    T g0 = g_[0], p0 = p_[0];
+    if (fabsf(val(g0) - val(p0)) > 180.0f) {  // standardize_spherical_box :236-257
+        g0 = m_fmod(g0 + 180.0f, 360.0f);
+        p0 = m_fmod(p0 + 180.0f, 360.0f);
     }
     const float hpi = (float)(3.141592653589793 / 2);
-    float thg = g0 * kDeg2Rad - kPi, phg = hpi - g_[1] * kDeg2Rad;  // 'convention' :217-234
-    float thp = p0 * kDeg2Rad - kPi, php = hpi - p_[1] * kDeg2Rad;
-    float phi_i = (phg + php) / 2.0f;
-    float phg_ = phg - phi_i, php_ = php - phi_i;
-    float dphi = fabsf(phg - php), dth = fabsf(thg - thp);
-    float s1 = sinf(dphi / 2.0f), s2 = sinf(dth / 2.0f);
-    float L = 2.0f * asinf(sqrtf(s1 * s1 + (cosf(phg) * cosf(php)) * (s2 * s2)));  // :63-66
-    float sl = sinf(L / 2.0f);
-    float q = (sl * sl - s1 * s1) / (cosf(phg_) * cosf(php_));
-    float dth_ = fabsf(2.0f * asinf(sqrtf(q)));  // :70-72 (NaN for q < 0, as in the reference)
-    float sgn = thp > thg ? 1.0f : -1.0f;
-    float mg = g0 * kDeg2Rad, mp = p0 * kDeg2Rad, pg = g_[1] * kDeg2Rad, pp = p_[1] * kDeg2Rad;  // 'math'
-    float mid = (mg + mp) / 2.0f;
-    og.x = 0.0f;       og.y = phg_;
+    T thg = g0 * kDeg2Rad - kPi, phg = hpi - g_[1] * kDeg2Rad;  // 'convention' :217-234
+    T thp = p0 * kDeg2Rad - kPi, php = hpi - p_[1] * kDeg2Rad;
+    T phi_i = (phg + php) / 2.0f;
+    T phg_ = phg - phi_i, php_ = php - phi_i;
+    T dphi = m_abs(phg - php), dth = m_abs(thg - thp);
+    T s1 = m_sin(dphi / 2.0f), s2 = m_sin(dth / 2.0f);
+    T L = 2.0f * m_asin(m_sqrt(s1 * s1 + (m_cos(phg) * m_cos(php)) * (s2 * s2)));  // :63-66
+    T sl = m_sin(L / 2.0f);
+    T q = (sl * sl - s1 * s1) / (m_cos(phg_) * m_cos(php_));
+    T dth_ = m_abs(2.0f * m_asin(m_sqrt(q)));  // :70-72 (NaN for q < 0, as in the reference)
+    float sgn = val(thp) > val(thg) ? 1.0f : -1.0f;
+    T mg = g0 * kDeg2Rad, mp = p0 * kDeg2Rad, pg = g_[1] * kDeg2Rad, pp = p_[1] * kDeg2Rad;  // 'math'
+    T mid = (mg + mp) / 2.0f;
+    og.x = g0 * 0.0f;  og.y = phg_;
     op.x = dth_ * sgn; op.y = php_;
     og.w = edge_length(g_[2] * kDeg2Rad, edge); og.h = edge_length(g_[3] * kDeg2Rad, edge);
     op.w = edge_length(p_[2] * kDeg2Rad, edge); op.h = edge_length(p_[3] * kDeg2Rad, edge);
@@ -274,11 +325,38 @@ SPH_DEV void transform_legacy(const float (&g_)[5], const float (&p_)[5], int ed
     op.a = legacy_angle_aux(mp, pp, mid, pp) * kDeg2Rad;
 }
 
-template <int VARIANT, int DIM>
-SPH_DEV void transform(const float (&g)[5], const float (&p)[5], int edge, int angle, PBox& og, PBox& op) {
+template <int VARIANT, int DIM, class T>
+SPH_DEV void transform(const T (&g)[5], const T (&p)[5], int edge, int angle, PBoxT<T>& og, PBoxT<T>& op) {
     if (VARIANT == VARIANT_STANDARD) transform_standard<DIM>(g, p, edge, angle, og, op);
     else if (VARIANT == VARIANT_EFFICIENT) transform_efficient<DIM>(g, p, edge, angle, og, op);
     else if (VARIANT == VARIANT_LEGACY) transform_legacy(g, p, edge, og, op);
+}
+
+// Adjoint of transform<VARIANT, DIM> by forward-mode differentiation (one pass per input coordinate: 2 * DIM passes of
+// the reference-order transform on Dual numbers): gin = J^T gout.  For the transforms without a closed-form backward
+// (sph2pob_legacy, rbb_angle='project'); the standard / efficient equator transforms use pair_transform_bwd.
+// `jitter`: the caller's transform ran jitter_spherical before and jitter_rotated after (Sph2PobTransfrom): both only
+// add constants and clamp, so they gate derivatives (torch.clamp: 1 on the closed interval) and shift the evaluation
+// point, which is handled by evaluating the transform on the jittered inputs.
+template <int VARIANT, int DIM>
+SPH_DEV void transform_bwd_dual(const float (&in1)[5], const float (&in2)[5], const float (&g1)[5], const float (&g2)[5],
+                                int edge, int angle, float (&gin1)[5], float (&gin2)[5]) {
+#pragma unroll 1
+    for (int k = 0; k < 2 * DIM; k++) {
+        Dual x[5], y[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            x[c] = Dual{in1[c], (k < DIM && c == k) ? 1.0f : 0.0f};
+            y[c] = Dual{in2[c], (k >= DIM && c == k - DIM) ? 1.0f : 0.0f};
+        }
+        PBoxT<Dual> p1, p2;
+        transform<VARIANT, DIM>(x, y, edge, angle, p1, p2);
+        const float acc = ((g1[0] * p1.x.d + g1[1] * p1.y.d) + (g1[2] * p1.w.d + g1[3] * p1.h.d) + g1[4] * p1.a.d) +
+                          ((g2[0] * p2.x.d + g2[1] * p2.y.d) + (g2[2] * p2.w.d + g2[3] * p2.h.d) + g2[4] * p2.a.d);
+        if (k < DIM) gin1[k] = acc; else gin2[k - DIM] = acc;
+    }
+#pragma unroll
+    for (int c = DIM; c < 5; c++) { gin1[c] = 0.0f; gin2[c] = 0.0f; }
 }
 
 // ------------------------------------------------------------------------------------------------
