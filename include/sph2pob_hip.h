@@ -112,11 +112,12 @@ int sph2pob_transform_bwd_f32(const float* b1, const float* b2, const float* gra
  * rbb_angle = 'project' of sph2pob_standard / sph2pob_efficient (sphdet/iou/sph2pob_legacy.py:8-31,
  * sph2pob_standard.py:88-108, sph2pob_efficient.py:81-97: the reference differentiates them with torch autograd) — by
  * forward-mode differentiation of the reference-order transform (2 * box_dim passes on (value, derivative) pairs).
- * No jitter (the Sph2PobTransfrom decorator, the only jittered caller, uses sph2pob_standard with 'equator').
+ * jitter != 0: the adjoint of jitter_spherical -> transform -> jitter_rotated (Sph2PobTransfrom('sph2pob_legacy'),
+ * sphdet/losses/sph2pob_transform.py:12-16, :28-30).
  */
 int sph2pob_transform_bwd_general_f32(const float* b1, const float* b2, const float* grad_planar1,
                                       const float* grad_planar2, float* grad_b1, float* grad_b2, int64_t n, int box_dim,
-                                      int variant, int edge, int angle, void* stream);
+                                      int variant, int edge, int angle, int jitter, void* stream);
 
 /*
  * Planar rotated-rectangle IoU on GIVEN planar boxes (x, y, w, h, a [rad]) — the op the reference obtains from mmcv

@@ -373,6 +373,31 @@ def transform_bwd_only():
                     torch.set_default_dtype(torch.float32)
                 arrs.update({key + 'b1': g, key + 'b2': p, key + 'go1': go1, key + 'go2': go2, key + 'p1': q1, key + 'p2': q2,
                              key + 'g1': ga, key + 'g2': gb, key + 'g1_64': ga64, key + 'g2_64': gb64})
+    # the jittered form the Sph2PobTransfrom('sph2pob_legacy') decorator runs (sph2pob_transform.py:25-30): clone,
+    # jiter_spherical_bboxes, sph2pob_legacy(..., 'rad'), jiter_rotated_bboxes — near-identical pairs included so that the
+    # jitters' branches and clamps take part
+    for near in (False, True):
+        g, p = gen(300, box='bfov', near=near)
+        if near:
+            p[:60] = g[:60] + torch.randn(60, 4) * 1e-4
+        go1, go2 = torch.randn(300, 5), torch.randn(300, 5)
+        key = f'legacyjit_bfov_{"near" if near else "uni"}_arc_'
+
+        def runj(gg, pp, o1, o2):
+            a, b = gg.clone().requires_grad_(True), pp.clone().requires_grad_(True)
+            x, y = R.api.jiter_spherical_bboxes(a.clone(), b.clone())
+            q1, q2 = R.leg.sph2pob_legacy(x, y, rbb_angle_version='rad')
+            q1, q2 = R.api.jiter_rotated_bboxes(q1, q2)
+            ((q1 * o1).sum() + (q2 * o2).sum()).backward()
+            return q1.detach(), q2.detach(), a.grad, b.grad
+        q1, q2, ga, gb = runj(g, p, go1, go2)
+        torch.set_default_dtype(torch.float64)
+        try:
+            _, _, ga64, gb64 = runj(g.double(), p.double(), go1.double(), go2.double())
+        finally:
+            torch.set_default_dtype(torch.float32)
+        arrs.update({key + 'b1': g, key + 'b2': p, key + 'go1': go1, key + 'go2': go2, key + 'p1': q1, key + 'p2': q2,
+                     key + 'g1': ga, key + 'g2': gb, key + 'g1_64': ga64, key + 'g2_64': gb64})
     save('transform_bwd', **arrs)
 
 

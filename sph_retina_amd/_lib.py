@@ -37,7 +37,7 @@ SIGNATURES = {
     'sph2pob_transform_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _int, _int, _int, _int,
                               ctypes.c_void_p],
     'sph2pob_transform_bwd_f32': [_c_f32p] * 6 + [_i64, _int, _int, _int, _int, ctypes.c_void_p],
-    'sph2pob_transform_bwd_general_f32': [_c_f32p] * 6 + [_i64, _int, _int, _int, _int, ctypes.c_void_p],
+    'sph2pob_transform_bwd_general_f32': [_c_f32p] * 6 + [_i64, _int, _int, _int, _int, _int, ctypes.c_void_p],
     'sph2pob_loss_fwd_f32': [_c_f32p, _c_f32p, _c_f32p, _int, ctypes.c_float, _c_f32p, _c_f32p, _i64, _int, _int,
                              ctypes.c_float,
                              ctypes.c_void_p],

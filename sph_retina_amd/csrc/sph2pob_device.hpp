@@ -137,50 +137,51 @@ template <class T> SPH_DEV T edge_length(T fov, int edge) {  // sph2pob_standard
 
 // ------------------------------------------------------------------------------------------------
 // jiter_spherical_bboxes — sph_iou_api.py:244-260.  b1/b2 are register copies (inputs are never mutated).
-template <int DIM>
-SPH_DEV void jitter_spherical(float (&b1)[5], float (&b2)[5]) {
+template <int DIM, class T>
+SPH_DEV void jitter_spherical(T (&b1)[5], T (&b2)[5]) {
     const float eps = (float)kEpsS, eps2 = (float)(2 * kEpsS);
     bool similar = false;
 #pragma unroll
-    for (int k = 0; k < DIM; k++) similar |= fabsf(b1[k] - b2[k]) < eps;
+    for (int k = 0; k < DIM; k++) similar |= fabsf(val(b1[k]) - val(b2[k])) < eps;
     const float sh1 = similar ? eps2 : 0.0f, sh2 = similar ? eps : 0.0f;  // x - 0 == x exactly
 #pragma unroll
     for (int k = 0; k < DIM; k++) {
         b1[k] = b1[k] - sh1;
         b2[k] = b2[k] + sh2;
     }
-    b1[0] = clampf(b1[0], eps2, (float)(360.0 - kEpsS));
-    b2[0] = clampf(b2[0], eps, (float)(360.0 - 2 * kEpsS));
+    b1[0] = m_clamp(b1[0], eps2, (float)(360.0 - kEpsS));
+    b2[0] = m_clamp(b2[0], eps, (float)(360.0 - 2 * kEpsS));
 #pragma unroll
     for (int k = 1; k < 4; k++) {
-        b1[k] = clampf(b1[k], eps2, (float)(180.0 - kEpsS));
-        b2[k] = clampf(b2[k], eps, (float)(180.0 - 2 * kEpsS));
+        b1[k] = m_clamp(b1[k], eps2, (float)(180.0 - kEpsS));
+        b2[k] = m_clamp(b2[k], eps, (float)(180.0 - 2 * kEpsS));
     }
     if (DIM == 5) {  // quirk kept: only bboxes2's gamma is clamped (twice) :256-258
-        b2[4] = clampf(b2[4], (float)(-360.0 + kEpsS), (float)(360.0 - 2 * kEpsS));
-        b2[4] = clampf(b2[4], (float)(-360.0 + 2 * kEpsS), (float)(360.0 - kEpsS));
+        b2[4] = m_clamp(b2[4], (float)(-360.0 + kEpsS), (float)(360.0 - 2 * kEpsS));
+        b2[4] = m_clamp(b2[4], (float)(-360.0 + 2 * kEpsS), (float)(360.0 - kEpsS));
     }
 }
 
 // jiter_rotated_bboxes — sph_iou_api.py:222-242
-SPH_DEV void jitter_rotated(PBox& p1, PBox& p2) {
+template <class T>
+SPH_DEV void jitter_rotated(PBoxT<T>& p1, PBoxT<T>& p2) {
     const float e = (float)kEpsS, e2 = (float)(2 * kEpsS), e5 = (float)(5 * kEpsS);
-    bool similar = (fabsf(p1.x - p2.x) < e) | (fabsf(p1.w - p2.w) < e) | (fabsf(p1.h - p2.h) < e) |
-                   (fabsf(p1.a - p2.a) < e);
+    bool similar = (fabsf(val(p1.x) - val(p2.x)) < e) | (fabsf(val(p1.w) - val(p2.w)) < e) | (fabsf(val(p1.h) - val(p2.h)) < e) |
+                   (fabsf(val(p1.a) - val(p2.a)) < e);
     if (similar) {
-        p1.x += e;  p1.y += e;  p1.w += e2; p1.h += e2; p1.a += e;
-        p2.x += e2; p2.y += e2; p2.w += e;  p2.h += e;  p2.a += e5;
+        p1.x = p1.x + e;  p1.y = p1.y + e;  p1.w = p1.w + e2; p1.h = p1.h + e2; p1.a = p1.a + e;
+        p2.x = p2.x + e2; p2.y = p2.y + e2; p2.w = p2.w + e;  p2.h = p2.h + e;  p2.a = p2.a + e5;
     }
     const float ea = (float)kEpsA, ea2 = (float)(2 * kEpsA);
-    if (fabsf(p1.a - p2.a) < ea) {
-        p1.a += ea;
-        p2.a += ea2;
+    if (fabsf(val(p1.a) - val(p2.a)) < ea) {
+        p1.a = p1.a + ea;
+        p2.a = p2.a + ea2;
     }
     const double pi = 3.141592653589793;
-    p1.w = fmaxf(p1.w, (float)(2 * kEpsA / 10)); p1.h = fmaxf(p1.h, (float)(2 * kEpsA / 10));
-    p2.w = fmaxf(p2.w, (float)(kEpsA / 10));     p2.h = fmaxf(p2.h, (float)(kEpsA / 10));
-    p1.a = clampf(p1.a, (float)(-2 * pi + 2 * kEpsA), (float)(2 * pi - kEpsA));
-    p2.a = clampf(p2.a, (float)(-2 * pi + kEpsA), (float)(2 * pi - 2 * kEpsA));
+    p1.w = m_max(p1.w, (float)(2 * kEpsA / 10)); p1.h = m_max(p1.h, (float)(2 * kEpsA / 10));
+    p2.w = m_max(p2.w, (float)(kEpsA / 10));     p2.h = m_max(p2.h, (float)(kEpsA / 10));
+    p1.a = m_clamp(p1.a, (float)(-2 * pi + 2 * kEpsA), (float)(2 * pi - kEpsA));
+    p2.a = m_clamp(p2.a, (float)(-2 * pi + kEpsA), (float)(2 * pi - 2 * kEpsA));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -335,12 +336,12 @@ SPH_DEV void transform(const T (&g)[5], const T (&p)[5], int edge, int angle, PB
 // Adjoint of transform<VARIANT, DIM> by forward-mode differentiation (one pass per input coordinate: 2 * DIM passes of
 // the reference-order transform on Dual numbers): gin = J^T gout.  For the transforms without a closed-form backward
 // (sph2pob_legacy, rbb_angle='project'); the standard / efficient equator transforms use pair_transform_bwd.
-// `jitter`: the caller's transform ran jitter_spherical before and jitter_rotated after (Sph2PobTransfrom): both only
-// add constants and clamp, so they gate derivatives (torch.clamp: 1 on the closed interval) and shift the evaluation
-// point, which is handled by evaluating the transform on the jittered inputs.
+// `jitter`: the caller's transform ran jitter_spherical before and jitter_rotated after (Sph2PobTransfrom with
+// 'sph2pob_legacy', sph2pob_transform.py:28-30): both only add constants and clamp, so on Dual numbers they shift the
+// evaluation point and gate derivatives (torch.clamp: 1 on the closed interval) like torch's in-place ops do.
 template <int VARIANT, int DIM>
 SPH_DEV void transform_bwd_dual(const float (&in1)[5], const float (&in2)[5], const float (&g1)[5], const float (&g2)[5],
-                                int edge, int angle, float (&gin1)[5], float (&gin2)[5]) {
+                                int edge, int angle, bool jitter, float (&gin1)[5], float (&gin2)[5]) {
 #pragma unroll 1
     for (int k = 0; k < 2 * DIM; k++) {
         Dual x[5], y[5];
@@ -350,7 +351,9 @@ SPH_DEV void transform_bwd_dual(const float (&in1)[5], const float (&in2)[5], co
             y[c] = Dual{in2[c], (k >= DIM && c == k - DIM) ? 1.0f : 0.0f};
         }
         PBoxT<Dual> p1, p2;
+        if (jitter) jitter_spherical<DIM>(x, y);
         transform<VARIANT, DIM>(x, y, edge, angle, p1, p2);
+        if (jitter) jitter_rotated(p1, p2);
         const float acc = ((g1[0] * p1.x.d + g1[1] * p1.y.d) + (g1[2] * p1.w.d + g1[3] * p1.h.d) + g1[4] * p1.a.d) +
                           ((g2[0] * p2.x.d + g2[1] * p2.y.d) + (g2[2] * p2.w.d + g2[3] * p2.h.d) + g2[4] * p2.a.d);
         if (k < DIM) gin1[k] = acc; else gin2[k - DIM] = acc;

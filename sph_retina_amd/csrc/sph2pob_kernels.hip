@@ -755,7 +755,7 @@ template <int VARIANT, int DIM>
 __global__ __launch_bounds__(kBlock) void transform_bwd_dual_kernel(const float* __restrict__ b1, const float* __restrict__ b2,
                                                                    const float* __restrict__ g1, const float* __restrict__ g2,
                                                                    float* __restrict__ gb1, float* __restrict__ gb2, int64_t n,
-                                                                   int edge, int angle) {
+                                                                   int edge, int angle, int jitter) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     float x[5], y[5], gx[5], gy[5], p[5], q[5];
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(kBlock) void transform_bwd_dual_kernel(const float*
     load_box<DIM>(b2, i, y);
 #pragma unroll
     for (int k = 0; k < 5; k++) { p[k] = g1[i * 5 + k]; q[k] = g2[i * 5 + k]; }
-    transform_bwd_dual<VARIANT, DIM>(x, y, p, q, edge, angle, gx, gy);
+    transform_bwd_dual<VARIANT, DIM>(x, y, p, q, edge, angle, jitter != 0, gx, gy);
 #pragma unroll
     for (int k = 0; k < DIM; k++) { gb1[i * DIM + k] = gx[k]; gb2[i * DIM + k] = gy[k]; }
 }
@@ -1199,7 +1199,7 @@ int sph2pob_transform_bwd_f32(const float* b1, const float* b2, const float* gra
 
 int sph2pob_transform_bwd_general_f32(const float* b1, const float* b2, const float* grad_planar1,
                                       const float* grad_planar2, float* grad_b1, float* grad_b2, int64_t n, int box_dim,
-                                      int variant, int edge, int angle, void* stream) {
+                                      int variant, int edge, int angle, int jitter, void* stream) {
     int rc = check_common(box_dim, variant, edge, angle);
     if (rc) return rc;
     const int v = variant & 0xff;
@@ -1210,7 +1210,7 @@ int sph2pob_transform_bwd_general_f32(const float* b1, const float* b2, const fl
     dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
     hipStream_t s = (hipStream_t)stream;
 #define SPH_TBWDD(V, D) \
-    hipLaunchKernelGGL((transform_bwd_dual_kernel<V, D>), grid, dim3(kBlock), 0, s, b1, b2, grad_planar1, grad_planar2, grad_b1, grad_b2, n, edge, angle)
+    hipLaunchKernelGGL((transform_bwd_dual_kernel<V, D>), grid, dim3(kBlock), 0, s, b1, b2, grad_planar1, grad_planar2, grad_b1, grad_b2, n, edge, angle, jitter)
     if (v == SPH2POB_VARIANT_LEGACY) SPH_TBWDD(2, 4);
     else if (v == SPH2POB_VARIANT_STANDARD) { if (box_dim == 4) SPH_TBWDD(0, 4); else SPH_TBWDD(0, 5); }
     else { if (box_dim == 4) SPH_TBWDD(1, 4); else SPH_TBWDD(1, 5); }

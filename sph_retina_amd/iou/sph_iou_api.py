@@ -133,12 +133,10 @@ class _Sph2PobTransformFunction(torch.autograd.Function):
         gb1, gb2 = torch.empty_like(b1), torch.empty_like(b2)
         if n and (variant == 'legacy' or rbb_angle == 'project'):
             # no closed-form adjoint for these two: forward-mode differentiation of the reference-order transform
-            if jitter:
-                raise NotImplementedError('the jittered transform (Sph2PobTransfrom) exists for sph2pob_standard / equator only')
             g1, g2 = G.as_f32(g1), G.as_f32(g2)
             G.call('sph2pob_transform_bwd_general_f32', b1.device, G.ptr(b1), G.ptr(b2), G.ptr(g1), G.ptr(g2), G.ptr(gb1),
                    G.ptr(gb2), ctypes.c_int64(n), dim, G.VARIANTS[variant] & 0xff, G.EDGES[rbb_edge],
-                   G.ANGLES.get(rbb_angle, 0), G.stream_of(b1))
+                   G.ANGLES.get(rbb_angle, 0), int(bool(jitter)), G.stream_of(b1))
         elif n:
             g1, g2 = G.as_f32(g1), G.as_f32(g2)
             G.call('sph2pob_transform_bwd_f32', b1.device, G.ptr(b1), G.ptr(b2), G.ptr(g1), G.ptr(g2), G.ptr(gb1),

@@ -115,19 +115,19 @@ int harness_planar_iou(const float* p1, const float* p2, int64_t n, int mode, fl
 // adjoint of the reference-order transforms by forward-mode differentiation (legacy, rbb_angle='project')
 template <int V, int DIM>
 static void tbwd_dual_loop(const float* b1, const float* b2, const float* g1, const float* g2, int64_t n, int edge, int angle,
-                           float* o1, float* o2) {
+                           int jitter, float* o1, float* o2) {
     for (int64_t i = 0; i < n; i++) {
         float x[5] = {0, 0, 0, 0, 0}, y[5] = {0, 0, 0, 0, 0}, p[5], q[5], gx[5], gy[5];
         for (int k = 0; k < DIM; k++) { x[k] = b1[i * DIM + k]; y[k] = b2[i * DIM + k]; }
         for (int k = 0; k < 5; k++) { p[k] = g1[i * 5 + k]; q[k] = g2[i * 5 + k]; }
-        transform_bwd_dual<V, DIM>(x, y, p, q, edge, angle, gx, gy);
+        transform_bwd_dual<V, DIM>(x, y, p, q, edge, angle, jitter != 0, gx, gy);
         for (int k = 0; k < DIM; k++) { o1[i * DIM + k] = gx[k]; o2[i * DIM + k] = gy[k]; }
     }
 }
 extern "C" int harness_transform_bwd_general(const float* b1, const float* b2, const float* g1, const float* g2, int64_t n,
-                                             int dim, int variant, int edge, int angle, float* o1, float* o2) {
-    if (variant == 2) tbwd_dual_loop<2, 4>(b1, b2, g1, g2, n, edge, angle, o1, o2);
-    else if (variant == 0) { if (dim == 4) tbwd_dual_loop<0, 4>(b1, b2, g1, g2, n, edge, angle, o1, o2); else tbwd_dual_loop<0, 5>(b1, b2, g1, g2, n, edge, angle, o1, o2); }
-    else { if (dim == 4) tbwd_dual_loop<1, 4>(b1, b2, g1, g2, n, edge, angle, o1, o2); else tbwd_dual_loop<1, 5>(b1, b2, g1, g2, n, edge, angle, o1, o2); }
+                                             int dim, int variant, int edge, int angle, int jitter, float* o1, float* o2) {
+    if (variant == 2) tbwd_dual_loop<2, 4>(b1, b2, g1, g2, n, edge, angle, jitter, o1, o2);
+    else if (variant == 0) { if (dim == 4) tbwd_dual_loop<0, 4>(b1, b2, g1, g2, n, edge, angle, jitter, o1, o2); else tbwd_dual_loop<0, 5>(b1, b2, g1, g2, n, edge, angle, jitter, o1, o2); }
+    else { if (dim == 4) tbwd_dual_loop<1, 4>(b1, b2, g1, g2, n, edge, angle, jitter, o1, o2); else tbwd_dual_loop<1, 5>(b1, b2, g1, g2, n, edge, angle, jitter, o1, o2); }
     return 0;
 }
