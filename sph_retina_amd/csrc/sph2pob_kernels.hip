@@ -81,6 +81,10 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_kernel(const float* __rest
 // the survivors' raw boxes on its own LDS stack (ballot + prefix rank => conflict-free consecutive slots, no atomics,
 // no barriers: LDS operations of one wave are in order), and runs lean_finish only when 64 records are available, i.e.
 // on fully populated waves.  Leftovers of the 4 waves of a workgroup are merged once at the end.
+// Slices are grid-strided (slice = wave + k * waves).  A balanced workgroup-contiguous distribution (every workgroup
+// floor / ceil of S / G slices instead of 12 next to 8) was measured 10.5 us against 8.9 us at 1 M pairs: at any moment
+// the loads of all waves then span the whole 32 MB of input instead of one contiguous ~12 MB window, and the first data
+// arrives after 3.0 us instead of 1.85 us (per-wave time stamps, tools/stamp_timeline.py; equal from 2 M pairs up).
 // Stores: culled pairs write 0 from stage 0, survivors write from the finishing stage by index.
 // Variants built and measured on MI355X this round (1 M pairs; profiles/r02b_ablation_*.log):
 //   * a separating-axis reject after stage 1 + a second record stack so that the clip too runs on full waves (only
@@ -91,6 +95,17 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_kernel(const float* __rest
 //   * no carried state at all: one wave per 128-pair chunk, cull both slices, compact, finish (one pass at 81 % lane
 //     use, no workgroup merge, no barrier): 8.84 us against 8.96 us here at 1 M pairs, 56.9 against 55.1 us at 8 M;
 //     one lane per pair without compaction 10.3 us / 66.0 us (profiles/r02f_ab_*.log).
+#if defined(SPH_STAMPS)
+// DIAGNOSTIC BUILD ONLY (tools/stamp_timeline.py; never in the shipped library): per-wave time stamps of the dominant
+// kernel, s_memrealtime (100 MHz, chip-wide), written to a buffer of their own that nothing else reads.
+__device__ unsigned long long* g_stamps = nullptr;
+__device__ __forceinline__ void stamp(int wave_global, int k) {
+    if ((threadIdx.x & 63) == 0 && g_stamps) g_stamps[(size_t)wave_global * 8 + k] = __builtin_amdgcn_s_memrealtime();
+}
+#define SPH_STAMP(k) stamp(wave_global, k)
+#else
+#define SPH_STAMP(k)
+#endif
 constexpr int kQCap = 128;                    // per-wave stack capacity (<= 63 carried + 64 pushed)
 template <int DIM>
 struct WaveQueue {
@@ -134,6 +149,7 @@ __global__ __launch_bounds__(kBlock, REF ? 4 : (DIM == 4 ? 7 : 5)) void iou_alig
     const int nslices = (n + 63) >> 6;
     const int wave_global = blockIdx.x * (kBlock / 64) + wave, nwaves = gridDim.x * (kBlock / 64);
     int count = 0;  // wave-uniform stack height
+    SPH_STAMP(0);
     // one slice: cull, push the survivors, finish 64 of them when a full wave of records is available
     auto slice = [&](const float (&x)[5], const float (&y)[5], int sl) {
         const int i = sl * 64 + lane;
@@ -145,12 +161,14 @@ __global__ __launch_bounds__(kBlock, REF ? 4 : (DIM == 4 ? 7 : 5)) void iou_alig
         const unsigned long long m = __ballot(surv);
         if (surv) queue_store<DIM>(q, count + __popcll(m & ((1ull << lane) - 1ull)), x, y, i);
         count += __popcll(m);
+        if (sl == wave_global) SPH_STAMP(1);   // first slice culled: its data has arrived
         if (count >= 64) {  // wave-uniform
             count -= 64;
             wave_lds_fence();
             float u1[5], u2[5];
             const int j = queue_load<DIM>(q, count + lane, u1, u2);
             out[j] = REF ? pair_iou<VARIANT, DIM>(u1, u2, mode, edge, ANGLE_EQUATOR) : lean_finish<VARIANT, DIM>(u1, u2, mode, edge);
+            SPH_STAMP(4);   // (last) in-loop pass done
         }
     };
     auto fetch = [&](int sl, float (&x)[5], float (&y)[5]) {
@@ -177,8 +195,10 @@ __global__ __launch_bounds__(kBlock, REF ? 4 : (DIM == 4 ? 7 : 5)) void iou_alig
         }
     }
     // merge the < 64 leftovers of the four waves and finish them on as few, as full waves as possible
+    SPH_STAMP(2);   // loop done
     if (lane == 0) leftover[wave] = count;
     __syncthreads();
+    SPH_STAMP(3);   // workgroup barrier passed
     const int c0 = leftover[0], c1 = leftover[1], c2 = leftover[2], c3 = leftover[3];
     const int total = c0 + c1 + c2 + c3;   // <= 252: at most one chunk per wave
     if (wave * 64 < total) {
@@ -191,6 +211,7 @@ __global__ __launch_bounds__(kBlock, REF ? 4 : (DIM == 4 ? 7 : 5)) void iou_alig
             out[j] = REF ? pair_iou<VARIANT, DIM>(u1, u2, mode, edge, ANGLE_EQUATOR) : lean_finish<VARIANT, DIM>(u1, u2, mode, edge);
         }
     }
+    SPH_STAMP(5);   // wave done
 }
 
 // ---- pairwise IoU for the assigner call pattern (few rows x many columns), closed-form core ----
@@ -1217,5 +1238,12 @@ int sph2pob_transform_bwd_general_f32(const float* b1, const float* b2, const fl
 #undef SPH_TBWDD
     return launch_status();
 }
+
+#if defined(SPH_STAMPS)
+int sph2pob_debug_set_stamps(void* buffer) {
+    unsigned long long* p = (unsigned long long*)buffer;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p));
+}
+#endif
 
 }  // extern "C"
