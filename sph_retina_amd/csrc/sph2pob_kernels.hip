@@ -94,7 +94,11 @@ __global__ __launch_bounds__(kBlock) void iou_aligned_kernel(const float* __rest
 //     12.1 us, deferred to an index stack and finished once per workgroup 11.0 us — hence lean_front's guarded blocks;
 //   * no carried state at all: one wave per 128-pair chunk, cull both slices, compact, finish (one pass at 81 % lane
 //     use, no workgroup merge, no barrier): 8.84 us against 8.96 us here at 1 M pairs, 56.9 against 55.1 us at 8 M;
-//     one lane per pair without compaction 10.3 us / 66.0 us (profiles/r02f_ab_*.log).
+//     one lane per pair without compaction 10.3 us / 66.0 us (profiles/r02f_ab_*.log);
+//   * one survivor ring per WORKGROUP (LDS slot reservation with ds_add_rtn, per-chunk fill counters, chunks claimed by
+//     compare-and-swap, slots recycled in order) so that a pass can start as soon as the workgroup holds 64 survivors and
+//     all passes but one are full: bit-identical results, 14.2 us / 75.2 us — three dependent LDS round trips and
+//     lane-0 sections per slice cost far more than the earlier start gains (profiles/r02i_ab_ring.log).
 #if defined(SPH_STAMPS)
 // DIAGNOSTIC BUILD ONLY (tools/stamp_timeline.py; never in the shipped library): per-wave time stamps of the dominant
 // kernel, s_memrealtime (100 MHz, chip-wide), written to a buffer of their own that nothing else reads.
