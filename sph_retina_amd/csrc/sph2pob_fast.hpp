@@ -67,7 +67,11 @@ SPH_DEV void sincos_r(float x, float& s, float& c) {
     float sp = fmaf(r * z, ps, r);
     float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
     float cp = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
-    int q = (int)k & 3;
+#if defined(__HIP_DEVICE_COMPILE__)
+    int q = (int)k & 3;                         // v_cvt_i32_f32 saturates (NaN -> 0): defined on the device
+#else
+    int q = (k == k ? (int)k : 0) & 3;          // the host build (unit tests, UBSan): a NaN angle must not reach the cast
+#endif
     float a = (q & 1) ? cp : sp;
     float b = (q & 1) ? sp : cp;
     s = (q & 2) ? -a : a;

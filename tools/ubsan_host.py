@@ -48,4 +48,14 @@ for dim in (4, 5):
         for m in range(4):
             for f in (0, 1):
                 lib.harness_loss(p(b1), p(b2), ctypes.c_int64(n), dim, m, ctypes.c_float(1e-6), p(loss), p(iou), p(gp), p(gt), f)
+        # adjoints of the transforms: closed form (standard / efficient) and forward-mode (legacy, project; +- jitter)
+        g1, g2 = np.ones((n, 5), np.float32), np.full((n, 5), -0.5, np.float32)
+        o1, o2 = np.empty((n, dim), np.float32), np.empty((n, dim), np.float32)
+        for v in (0, 1):
+            for jit in (0, 1):
+                lib.harness_transform_bwd(p(b1), p(b2), p(g1), p(g2), ctypes.c_int64(n), dim, v, 0, jit, p(o1), p(o2))
+                lib.harness_transform_bwd_general(p(b1), p(b2), p(g1), p(g2), ctypes.c_int64(n), dim, v, 1, 1, jit, p(o1), p(o2))
+        if dim == 4:
+            for jit in (0, 1):
+                lib.harness_transform_bwd_general(p(b1), p(b2), p(g1), p(g2), ctypes.c_int64(n), 4, 2, 0, 0, jit, p(o1), p(o2))
         print(dim, name, 'ok', flush=True)
