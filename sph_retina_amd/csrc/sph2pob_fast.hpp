@@ -280,7 +280,11 @@ SPH_DEV bool cull_pair(const CullBox& g, const CullBox& p) {
 // and the 1.5e-3 rad margin moved into R^2: (R0 + m)^2 <= R0^2 + 3 m + m^2 for R0 < 3 (cos R's polynomial lower bound
 // decreases in R^2 on the whole range, so a larger R^2 only culls less).  A degenerate box (d = 0) gives 0 * inf = NaN
 // and is never culled, like the +inf radius of cull_box.
-template <int DIM>
+// CHORD (sph2pob_legacy): that transform places the planar centres at a distance d with d >= 2 sin(L / 2), the chord of
+// the great-circle distance L, not at L itself (d^2 / 4 = t^2 + b^2 >= sin^2 t + sin^2 b >= sin^2(L / 2) with b = half the
+// latitude difference and sin t = sqrt(sin^2(L/2) - sin^2 b) / cos b: sph2pob_legacy.py:38-83), so the circles are
+// certainly apart only when the chord exceeds the sum of the radii: cos L < 1 - R^2 / 2.
+template <int DIM, bool CHORD = false>
 SPH_DEV bool fast_cull(const float (&g)[5], const float (&p)[5], int edge) {
 #pragma clang fp contract(fast)
     // scale first, clamp second: the product is a canonical number, so the compiler does not have to quiet a possible
@@ -301,6 +305,7 @@ SPH_DEV bool fast_cull(const float (&g)[5], const float (&p)[5], int edge) {
     const float cD = hw_cos_rev(thp - thg);
     float C = 0.5f * ((u + v) + (u - v) * cD);
     if (DIM == 5) C = fmaf(g[4] + p[4], 0.0f, C);   // a NaN / infinite gamma must not be culled either
+    if (CHORD) return (R2 < 3.9f) & (C < fmaf(-0.5f, R2, 1.0f) - 1e-4f);
     return (R2 < 8.9f) & (C < cosR_lb - 1e-4f);
 }
 

@@ -138,8 +138,9 @@ __device__ __forceinline__ void wave_lds_fence() {
 // ARC: rbb_edge == 'arc' folded at compile time (the chord / tangent forms pull ocml's sinf / tanf argument reduction
 // into the cull and the finishing stage: 8 copies of ~100 instructions the common launch never executes)
 // REF: finish with the reference-order arithmetic (pair_iou) instead of the closed-form core: the cull is exact for it as
-// well (disjoint planar rectangles give exactly 0 in the reference), so `set_arithmetic('reference')` pays its ~3x VALU
-// only for the survivors, on full waves.
+// well (disjoint planar rectangles give exactly 0 in the reference), so `set_arithmetic('reference')`, rbb_angle='project'
+// (same planar sizes and positions, other angles: the circles do not change) and sph2pob_legacy (VARIANT 2: chord form of
+// the cull) pay their ~3x VALU only for the survivors, on full waves.
 template <int VARIANT, int DIM, bool PREFETCH, bool ARC, bool REF = false>
 __global__ __launch_bounds__(kBlock, REF ? 4 : (DIM == 4 ? 7 : 5)) void iou_aligned_compact_kernel(const float* __restrict__ b1,
                                                                                       const float* __restrict__ b2,
@@ -147,19 +148,24 @@ __global__ __launch_bounds__(kBlock, REF ? 4 : (DIM == 4 ? 7 : 5)) void iou_alig
                                                                                       int mode, int edge_arg) {
     __shared__ WaveQueue<DIM> queues[kBlock / 64];
     __shared__ int leftover[kBlock / 64];
-    const int edge = ARC ? (int)EDGE_ARC : edge_arg;
+    const int edge = ARC ? (int)EDGE_ARC : (edge_arg & 0xff);
+    const int angle = REF ? (edge_arg >> 8) & 1 : (int)ANGLE_EQUATOR;   // reference-order finish only: rbb_angle
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     WaveQueue<DIM>& q = queues[wave];
     const int nslices = (n + 63) >> 6;
     const int wave_global = blockIdx.x * (kBlock / 64) + wave, nwaves = gridDim.x * (kBlock / 64);
     int count = 0;  // wave-uniform stack height
+    auto finish = [&](const float (&u1)[5], const float (&u2)[5]) -> float {
+        if constexpr (REF) return pair_iou<VARIANT, DIM>(u1, u2, mode, edge, angle);
+        else return lean_finish<VARIANT, DIM>(u1, u2, mode, edge);
+    };
     SPH_STAMP(0);
     // one slice: cull, push the survivors, finish 64 of them when a full wave of records is available
     auto slice = [&](const float (&x)[5], const float (&y)[5], int sl) {
         const int i = sl * 64 + lane;
         bool surv = false;
         if (i < n) {
-            if (fast_cull<DIM>(x, y, edge)) out[i] = 0.0f;
+            if (fast_cull<DIM, VARIANT == VARIANT_LEGACY>(x, y, edge)) out[i] = 0.0f;
             else surv = true;
         }
         const unsigned long long m = __ballot(surv);
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(kBlock, REF ? 4 : (DIM == 4 ? 7 : 5)) void iou_alig
             wave_lds_fence();
             float u1[5], u2[5];
             const int j = queue_load<DIM>(q, count + lane, u1, u2);
-            out[j] = REF ? pair_iou<VARIANT, DIM>(u1, u2, mode, edge, ANGLE_EQUATOR) : lean_finish<VARIANT, DIM>(u1, u2, mode, edge);
+            out[j] = finish(u1, u2);
             SPH_STAMP(4);   // (last) in-loop pass done
         }
     };
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(kBlock, REF ? 4 : (DIM == 4 ? 7 : 5)) void iou_alig
             if (k >= c0) { k -= c0; w = 1; if (k >= c1) { k -= c1; w = 2; if (k >= c2) { k -= c2; w = 3; } } }
             float u1[5], u2[5];
             const int j = queue_load<DIM>(queues[w], k, u1, u2);
-            out[j] = REF ? pair_iou<VARIANT, DIM>(u1, u2, mode, edge, ANGLE_EQUATOR) : lean_finish<VARIANT, DIM>(u1, u2, mode, edge);
+            out[j] = finish(u1, u2);
         }
     }
     SPH_STAMP(5);   // wave done
@@ -826,7 +832,7 @@ struct AlignedLaunch {
     const float *b1, *b2; float* out; int64_t n; int mode, edge, angle; hipStream_t s; bool fast = true;
     template <int V, int D> int run() {
         dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-        if (V < 2 && angle == SPH2POB_ANGLE_EQUATOR && n < ((int64_t)1 << 31) - 64 && !g_no_compact) {
+        if (V <= 2 && n < ((int64_t)1 << 31) - 64 && !g_no_compact) {
             // persistent-style grid.  Measured on MI355X (tools/sweep_slices.sh): every CU must hold the same number of
             // workgroups (1 303 workgroups = 5.09 per CU take 12 % longer than 1 536 = 6 per CU); 6 per CU (24 waves per CU)
             // is the best or within noise of the best from 125 k to 8 M pairs; small launches want one slice per wave
@@ -841,9 +847,11 @@ struct AlignedLaunch {
             else if (wgs > kCUs) { wgs = (wgs + kCUs - 1) / kCUs * kCUs; if (wgs > kCUs * resident) wgs = kCUs * resident; }
             if (g_wgs_per_cu > 0) wgs = kCUs * g_wgs_per_cu;
             if (wgs < 1) wgs = 1;
-            constexpr int VV = V >= 2 ? 0 : V;
-#define SPH_PIPE(PF, ARC, REF) hipLaunchKernelGGL((iou_aligned_compact_kernel<VV, D, PF, ARC, REF>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge)
-            if (!fast) { if (wgs > kCUs * 4) wgs = kCUs * 4; SPH_PIPE(true, false, true); }   // reference-order finish: 4 waves per SIMD
+            constexpr int VV = V > 2 ? 0 : V;
+            const bool ref_finish = !fast || V == 2 || angle != SPH2POB_ANGLE_EQUATOR;
+            const int edge_k = edge | (angle << 8);
+#define SPH_PIPE(PF, ARC, REF) hipLaunchKernelGGL((iou_aligned_compact_kernel<VV, D, PF, ARC, REF>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge_k)
+            if (ref_finish) { if (wgs > kCUs * 4) wgs = kCUs * 4; SPH_PIPE(true, false, true); }   // reference-order finish: 4 waves per SIMD
             else if (edge == SPH2POB_EDGE_ARC) { if (g_prefetch) SPH_PIPE(true, true, false); else SPH_PIPE(false, true, false); }
             else { if (g_prefetch) SPH_PIPE(true, false, false); else SPH_PIPE(false, false, false); }
 #undef SPH_PIPE

@@ -131,3 +131,16 @@ extern "C" int harness_transform_bwd_general(const float* b1, const float* b2, c
     else { if (dim == 4) tbwd_dual_loop<1, 4>(b1, b2, g1, g2, n, edge, angle, jitter, o1, o2); else tbwd_dual_loop<1, 5>(b1, b2, g1, g2, n, edge, angle, jitter, o1, o2); }
     return 0;
 }
+
+// stage-0 cull decisions (1 = culled): the arc form (standard / efficient) and the chord form (legacy)
+extern "C" int harness_cull(const float* b1, const float* b2, int64_t n, int dim, int chord, unsigned char* out) {
+    for (int64_t i = 0; i < n; i++) {
+        float x[5] = {0, 0, 0, 0, 0}, y[5] = {0, 0, 0, 0, 0};
+        for (int k = 0; k < dim; k++) { x[k] = b1[i * dim + k]; y[k] = b2[i * dim + k]; }
+        bool c;
+        if (dim == 4) c = chord ? fast_cull<4, true>(x, y, EDGE_ARC) : fast_cull<4, false>(x, y, EDGE_ARC);
+        else c = chord ? fast_cull<5, true>(x, y, EDGE_ARC) : fast_cull<5, false>(x, y, EDGE_ARC);
+        out[i] = c ? 1 : 0;
+    }
+    return 0;
+}

@@ -317,3 +317,32 @@ def test_default_arithmetic_fixed_bounds_per_stratum_1m(S, oracle, box, dist, va
     assert r['mean'] < (1e-7 if dist == 'uniform' else 2.5e-6)
     if dist == 'uniform':   # the benchmark distribution: everything within 1e-4, all but a handful within 1e-5
         assert r['max'] < 1e-4 and t['max'] < 5e-5, (r, t)
+
+
+def test_full_size_properties_8m_and_sharded_assembly(S, oracle):
+    """BASELINE configs[4]'s batch on ONE GPU (8,000,000 BFoV pairs, the default arithmetic): size-independent properties,
+    and the multi-GPU contract rehearsed on one device — evaluating the 8 contiguous shards that 8 ranks would own and
+    concatenating them (what the all-gather assembles) gives the single-launch result bit for bit."""
+    S.set_arithmetic('fast')
+    n = 8_000_000
+    g = torch.Generator(device='cpu').manual_seed(4)
+    u = torch.rand((2, n, 4), generator=g)
+    mk = lambda v: torch.stack([v[:, 0] * 360, v[:, 1] * 180, v[:, 2] * 99 + 1, v[:, 3] * 99 + 1], 1).cuda()  # noqa: E731
+    b1, b2 = mk(u[0]), mk(u[1])
+    iou = S.sph2pob_standard_iou(b1, b2, is_aligned=True)
+    assert iou.shape == (n,) and bool(torch.isfinite(iou).all())
+    assert float(iou.min()) >= 0 and float(iou.max()) <= 1
+    assert 0.255 < float((iou > 0).float().mean()) < 0.265       # 26 % of uniform pairs overlap
+    from sph_retina_amd.parallel import shard_bounds
+    parts = []
+    for r in range(8):
+        lo, hi = shard_bounds(n, 8, r)
+        parts.append(S.sph2pob_standard_iou(b1[lo:hi], b2[lo:hi], is_aligned=True))
+    assert torch.equal(torch.cat(parts), iou)
+    # ragged shards (3 ranks) too
+    assert torch.equal(torch.cat([S.sph2pob_standard_iou(b1[lo:hi], b2[lo:hi], is_aligned=True)
+                                  for lo, hi in (shard_bounds(n, 3, r) for r in range(3))]), iou)
+    idx = torch.randperm(n, device='cuda')[:50000]
+    ref = oracle.iou_aligned(b1[idx].cpu().numpy(), b2[idx].cpu().numpy(), variant='standard', planar='mmcv', nthreads=64)
+    d = np.abs(iou[idx].cpu().numpy() - ref)
+    assert d.mean() < 1e-7 and (d > 1e-5).sum() <= 5 and d.max() < 1e-4

@@ -80,3 +80,28 @@ def test_closed_form_path_rejects_are_exact_and_values_track_truth(host_harness,
             # no worse than the reference's own fp32 arithmetic against the exact value of its own formula
             assert err.mean() <= max(1e-6, 2.0 * noise.mean()), (name, v, err.mean(), noise.mean())
             assert (err > 1e-4).sum() <= max(1e-3 * err.size, 4 * (noise > 1e-4).sum()), (name, v, int((err > 1e-4).sum()), int((noise > 1e-4).sum()))
+
+
+@pytest.mark.parametrize('dim', [4, 5])
+def test_stage0_cull_is_exact_for_every_arithmetic_it_fronts(host_harness, oracle, dim):
+    """A culled pair is written as 0 without being looked at again, so the cull must only fire where the REFERENCE's own
+    fp32 evaluation gives exactly 0 (disjoint planar rectangles): the arc form in front of sph2pob_standard / efficient
+    (equator and project: same planar positions and sizes) and the chord form in front of sph2pob_legacy, whose planar
+    centre distance is only bounded below by the chord of the great-circle distance."""
+    O = oracle
+    culled_total = 0
+    for name, b1, b2 in _sets(O, dim, N):
+        arc = host_harness.cull(b1, b2)
+        for v, ang in (('standard', 'equator'), ('efficient', 'equator'), ('standard', 'project'), ('efficient', 'project')):
+            ref = O.iou_aligned(b1, b2, variant=v, angle=ang, planar='mmcv')
+            assert ref[arc].max(initial=0.0) == 0.0, (name, v, ang, float(ref[arc].max()))
+        culled_total += int(arc.sum())
+        if dim == 4:
+            chord = host_harness.cull(b1, b2, chord=True)
+            assert not (chord & ~arc).any()          # the chord form is the weaker one
+            ref = O.iou_aligned(b1, b2, variant='legacy', planar='mmcv')
+            ref = np.where(np.isfinite(ref), ref, 0.0)   # asin(sqrt(q < 0)): NaN in the reference, 0 here (DESIGN §3)
+            assert ref[chord].max(initial=0.0) == 0.0, (name, float(ref[chord].max()))
+            if name == 'uniform':
+                assert 0.45 < chord.mean() < arc.mean() < 0.65, (chord.mean(), arc.mean())
+    assert culled_total > 0
