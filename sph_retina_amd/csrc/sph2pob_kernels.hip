@@ -135,6 +135,16 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// The reference-order finish is 15-35 KB of code per copy (ocml's sinf / cosf / acosf / asinf expansions): called, not
+// inlined, so that the kernel's two call sites (loop and tail) share one copy and the kernel stays inside the 64 KB
+// instruction cache.
+template <int VARIANT, int DIM>
+__device__ __attribute__((noinline)) float ref_finish(float a0, float a1, float a2, float a3, float a4, float b0, float b1, float b2,
+                                                      float b3, float b4, int mode, int edge, int angle) {
+    const float u1[5] = {a0, a1, a2, a3, a4}, u2[5] = {b0, b1, b2, b3, b4};
+    return pair_iou<VARIANT, DIM>(u1, u2, mode, edge, angle);
+}
+
 // ARC: rbb_edge == 'arc' folded at compile time (the chord / tangent forms pull ocml's sinf / tanf argument reduction
 // into the cull and the finishing stage: 8 copies of ~100 instructions the common launch never executes)
 // REF: finish with the reference-order arithmetic (pair_iou) instead of the closed-form core: the cull is exact for it as
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(kBlock, REF ? 4 : (DIM == 4 ? 7 : 5)) void iou_alig
     const int wave_global = blockIdx.x * (kBlock / 64) + wave, nwaves = gridDim.x * (kBlock / 64);
     int count = 0;  // wave-uniform stack height
     auto finish = [&](const float (&u1)[5], const float (&u2)[5]) -> float {
-        if constexpr (REF) return pair_iou<VARIANT, DIM>(u1, u2, mode, edge, angle);
+        if constexpr (REF) return ref_finish<VARIANT, DIM>(u1[0], u1[1], u1[2], u1[3], u1[4], u2[0], u2[1], u2[2], u2[3], u2[4], mode, edge, angle);
         else return lean_finish<VARIANT, DIM>(u1, u2, mode, edge);
     };
     SPH_STAMP(0);
