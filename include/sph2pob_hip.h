@@ -174,6 +174,8 @@ int sph2pob_loss_fwd_sum_f32(const float* pred, const float* target, const float
  *     grad_target[i, :] = scale * w_i * dL_i / dtarget[i, :]      (optional, may be NULL)
  * i.e. the gradients for an upstream gradient of 1.  torch's backward then only scales them:
  * sph2pob_loss_grad_scale_f32: out[i, :] = stash[i, :] * grad_out[i * grad_stride]  (grad_stride 0: one scalar).
+ * out may be the stash itself (in place); in place with a scalar upstream gradient of exactly 1.0 — a plain
+ * `loss.backward()` — the launch returns after one scalar load per workgroup: the stash already is the gradient.
  */
 int sph2pob_loss_fwd_grad_f32(const float* pred, const float* target, const float* weight, int weight_dim, float scale,
                               float* loss, float* out_sum, float* workspace, float* grad_pred, float* grad_target,

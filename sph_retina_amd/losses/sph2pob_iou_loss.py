@@ -60,33 +60,44 @@ class _Sph2PobLossFunction(torch.autograd.Function):
                    None if reduce else (out.data_ptr() if n else None), out.data_ptr() if reduce else None,
                    ws.data_ptr() if reduce else None, gp.data_ptr() if n else None, gt.data_ptr() if need_t and n else None,
                    n, dim, mode_c, eps, stream)
-            ctx.save_for_backward(gp, gt)
+            ctx.save_for_backward(gp, gt, p, t, w)
+            ctx.first = True
         elif reduce:
             G.call('sph2pob_loss_fwd_sum_f32', dev, p.data_ptr() if n else None, t.data_ptr() if n else None, wp, wd, scale,
                    out.data_ptr(), G.loss_sum_workspace(dev, n).data_ptr(), n, dim, mode_c, eps, stream)
         elif n:
             G.call('sph2pob_loss_fwd_f32', dev, p.data_ptr(), t.data_ptr(), wp, wd, scale, out.data_ptr(), None, n, dim,
                    mode_c, eps, stream)
-        ctx.meta = (reduce, need_p, need_t, pred.dtype, target.dtype)
+        ctx.meta = (reduce, need_p, need_t, pred.dtype, target.dtype, mode_c, eps, scale, wd)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        gp, gt = ctx.saved_tensors
-        reduce, need_p, need_t, pdt, tdt = ctx.meta
+        gp, gt, p, t, w = ctx.saved_tensors
+        reduce, need_p, need_t, pdt, tdt, mode_c, eps, scale, wd = ctx.meta
         n, dim = gp.shape
         g = _f32c(grad_out)
         stream = G.raw_stream_of(gp.device)
+        if not ctx.first:
+            # a second backward through the same node (retain_graph=True): the stashes were scaled in place and handed to
+            # autograd by the first one — recompute with the two-pass backward kernel
+            ngp, ngt = torch.empty_like(p), (torch.empty_like(t) if need_t else None)
+            if n:
+                G.call('sph2pob_loss_bwd_f32', p.device, p.data_ptr(), t.data_ptr(), w.data_ptr() if w is not None else None, wd,
+                       g.data_ptr(), 0 if reduce else 1, scale, ngp.data_ptr(), ngt.data_ptr() if need_t else None, n, dim,
+                       mode_c, eps, stream)
+            return ((ngp if pdt is torch.float32 else ngp.to(pdt)) if need_p else None,
+                    (ngt if tdt is torch.float32 else ngt.to(tdt)) if need_t else None, None, None, None, None, None)
+        ctx.first = False
         outs = []
         for stash, need, dt in ((gp, need_p, pdt), (gt, need_t, tdt)):
             if not need or stash is None:
                 outs.append(None)
                 continue
-            o = torch.empty_like(stash)
-            if n:
+            if n:   # in place: with an upstream gradient of exactly 1 the launch returns at once, the stash IS the gradient
                 G.call('sph2pob_loss_grad_scale_f32', stash.device, stash.data_ptr(), g.data_ptr(), 0 if reduce else 1,
-                       o.data_ptr(), n, dim, stream)
-            outs.append(o if dt is torch.float32 else o.to(dt))
+                       stash.data_ptr(), n, dim, stream)
+            outs.append(stash if dt is torch.float32 else stash.to(dt))
         return outs[0], outs[1], None, None, None, None, None
 
 

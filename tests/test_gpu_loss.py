@@ -330,3 +330,38 @@ def test_c_abi_one_pass_and_two_pass_forms_agree(L, box, weighted):
     # argument validation
     assert lib.sph2pob_loss_fwd_grad_f32(p.data_ptr(), t.data_ptr(), None, 0, 1.0, None, None, None, None, None, n, dim, 0, 1e-6, st) == -1
     assert lib.sph2pob_loss_grad_scale_f32(gp1.data_ptr(), up.data_ptr(), 2, o1.data_ptr(), n, dim, st) == -3
+
+
+@pytest.mark.parametrize('reduction', ['mean', 'none'])
+def test_backward_twice_and_non_unit_upstream_gradients(L, reduction):
+    """The first backward scales the stashed gradients IN PLACE (a no-op launch for an upstream gradient of exactly 1, the
+    plain `loss.backward()`) and hands them to autograd; a second backward through the same node (retain_graph=True)
+    recomputes with the two-pass kernel.  Both must equal an independent evaluation for any upstream gradient."""
+    g = load_golden('loss_rbfov')
+    tgt = cu(g['target'])
+
+    def fresh(up):
+        p = cu(g['pred'], True)
+        out = L.Sph2PobIoULoss(mode='ciou', reduction=reduction)(p, tgt)
+        (out * up).sum().backward()
+        return p.grad.clone()
+    n = tgt.size(0)
+    ups = [1.0, 0.37, torch.linspace(0.5, 2.0, n).cuda() if reduction == 'none' else 3.0]
+    want = [fresh(u) for u in ups]
+    p = cu(g['pred'], True)
+    out = L.Sph2PobIoULoss(mode='ciou', reduction=reduction)(p, tgt)
+    for k, up in enumerate(ups):   # three backward passes through ONE forward
+        p.grad = None
+        (out * up).sum().backward(retain_graph=True)
+        assert torch.allclose(p.grad, want[k], rtol=3e-7, atol=1e-12), k
+    # the C entry itself, in place: unit gradient leaves the stash untouched, anything else scales it
+    from sph_retina_amd import _lib
+    lib = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    stash = torch.randn(1000, 5, device='cuda')
+    keep = stash.clone()
+    one, two = torch.ones((), device='cuda'), torch.full((), 2.0, device='cuda')
+    assert lib.sph2pob_loss_grad_scale_f32(stash.data_ptr(), one.data_ptr(), 0, stash.data_ptr(), 1000, 5, st) == 0
+    assert torch.equal(stash, keep)
+    assert lib.sph2pob_loss_grad_scale_f32(stash.data_ptr(), two.data_ptr(), 0, stash.data_ptr(), 1000, 5, st) == 0
+    assert torch.equal(stash, keep * 2)

@@ -79,7 +79,7 @@ def config3(n=1_000_000):
     def abi_step():   # what the autograd Function launches: forward + gradients in one pass, final sum, backward = scale
         lib.sph2pob_loss_fwd_grad_f32(G.ptr(p_), G.ptr(t_), null, 0, ctypes.c_float(1.0 / n), null, ctypes.c_void_p(out.data_ptr()),
                                       G.ptr(ws2), G.ptr(stash), null, nn, 5, 3, ctypes.c_float(1e-6), st)
-        lib.sph2pob_loss_grad_scale_f32(G.ptr(stash), ctypes.c_void_p(one.data_ptr()), 0, G.ptr(gp), nn, 5, st)
+        lib.sph2pob_loss_grad_scale_f32(G.ptr(stash), ctypes.c_void_p(one.data_ptr()), 0, G.ptr(stash), nn, 5, st)   # in place, g = 1
 
     def abi_step_two_pass():   # round 1's form: forward (+ sum), then a backward kernel that recomputes the forward
         lib.sph2pob_loss_fwd_sum_f32(G.ptr(p_), G.ptr(t_), null, 0, ctypes.c_float(1.0 / n), ctypes.c_void_p(out.data_ptr()),
