@@ -477,12 +477,12 @@ __global__ __launch_bounds__(kBlock) void loss_fwd_grad_kernel(const float* __re
 // out[i, :] = stash[i, :] * g[i * stride]: the whole of torch's backward after loss_fwd_grad_kernel
 __global__ __launch_bounds__(kBlock) void grad_scale_kernel(const float* stash, const float* __restrict__ g, int stride, float* out,
                                                            int64_t total, int dim) {   // out may alias stash (in place)
-    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     // in place with an upstream gradient of exactly 1 (a plain `loss.backward()`): the stash already is the gradient —
-    // one scalar load per workgroup instead of a 40 MB pass (the stash tensor itself is handed to autograd)
+    // one scalar load per workgroup instead of a 40 MB pass (the stash tensor itself is handed to autograd).  The grid is
+    // capped and strided so that this early exit costs a small launch, not the dispatch of 20 000 workgroups.
     if (stride == 0 && out == stash && g[0] == 1.0f) return;
-    if (e >= total) return;
-    out[e] = stash[e] * g[stride ? (e / dim) : 0];
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock)
+        out[e] = stash[e] * g[stride ? (e / dim) : 0];
 }
 
 // ---- deterministic two-pass sum (bitwise reproducible losses; no float atomics) ----
@@ -1194,7 +1194,10 @@ int sph2pob_loss_grad_scale_f32(const float* stash, const float* grad_out, int g
     if (n == 0) return SPH2POB_OK;
     if (!stash || !grad_out || !out) return SPH2POB_ERR_NULL;
     const int64_t total = n * box_dim;
-    hipLaunchKernelGGL(grad_scale_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+    int64_t blocks = (total + kBlock - 1) / kBlock;
+    const int64_t cap = (int64_t)cu_count() * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(grad_scale_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream,
                        stash, grad_out, grad_stride, out, total, box_dim);
     return launch_status();
 }
