@@ -959,10 +959,12 @@ struct PairwiseLaunch {
     template <int V, int D> int run() {
         if (fast && V < 2 && angle == SPH2POB_ANGLE_EQUATOR && n < ((int64_t)1 << 31) - kBlock && m <= (int64_t)65535 * 4 &&
             !g_no_compact) {
-            // rows per workgroup: as many as possible (amortises the per-column setup, fills the survivor stacks) while
-            // the grid still holds >= ~8 workgroups per CU
+            // rows per workgroup: enough to amortise the per-column setup and fill the survivor stacks, few enough that the
+            // grid holds thousands of workgroups (tools/sweep_pw_rows.sh, 64 GT: 98 208 anchors 27.6 us at 8 rows, 31.8 at
+            // 16, 46.7 at 32; 392 832 anchors 65.5 us at 8-16 rows, 74 at 32, 78 at 4)
             const int64_t col_tiles = (n + kBlock - 1) / kBlock;
-            int64_t rpw = g_pw_rows > 0 ? g_pw_rows : (m * col_tiles) / 3072;
+            int64_t rpw = g_pw_rows > 0 ? g_pw_rows : (m * col_tiles) / 8192;
+            if (rpw < 8 && g_pw_rows <= 0) rpw = 8;
             if (rpw < 4) rpw = 4;
             if (rpw > kPwRows) rpw = kPwRows;
             if (rpw > m) rpw = m;
