@@ -26,7 +26,7 @@ steps is reported next to it as `unsettled`), barrier + synchronize, exactly K t
 over ranks.
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel (iou_aligned_compact_kernel) against the HBM roofline: algorithmic bytes = 36 B/pair
+  roofline      the dominant kernel (iou_aligned_chunk_kernel) against the HBM roofline: algorithmic bytes = 36 B/pair
                 (2 x 16 B boxes in + 4 B IoU out) / average launch duration measured here with HIP events
                 on the launch stream.  `traffic` (PMC-measured HBM bytes per launch) and `valu_active_frac` come from
                 this round's committed rocprofv3 summary (separate --pmc passes) and are only attached when this run's
@@ -341,7 +341,7 @@ def main(argv=None):
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        kern = 'iou_aligned_compact_kernel' if args.arithmetic != 'reference' and args.variant != 'legacy' else 'iou_aligned_kernel'
+        kern = 'iou_aligned_chunk_kernel' if args.arithmetic != 'reference' and args.variant != 'legacy' else 'iou_aligned_compact_kernel'
         out = {
             'metric': 'box-pairs/sec, Sph2Pob spherical IoU (aligned BFoV, fp32), '
                       + (f'{total:,} pairs per launch on one MI355X' if world == 1 else

@@ -17,9 +17,10 @@ constexpr int kBlock = 256;  // 4 waves of 64 lanes
 constexpr int kCUsDefault = 256;  // MI355X in SPX mode: 8 XCDs x 32 CUs
 
 // tuning / A-B knobs (environment, read once at load): SPH2POB_NO_COMPACT=1 disables the compacting kernels,
-// SPH2POB_NO_PREFETCH=1 the register prefetch, SPH2POB_SLICES_PER_WAVE=s / SPH2POB_WGS_PER_CU=k override the aligned
-// kernel's grid rule (s slices per wave, or exactly k workgroups per CU), SPH2POB_PW_ROWS the pairwise kernel's rows
-// per workgroup
+// SPH2POB_ALIGNED_KERNEL=persistent selects the persistent form of the aligned kernel for the closed-form arithmetic
+// (the default is the one-round chunk form), SPH2POB_NO_PREFETCH=1 its register prefetch, SPH2POB_SLICES_PER_WAVE=s /
+// SPH2POB_WGS_PER_CU=k override its grid rule (s slices per wave, or exactly k workgroups per CU), SPH2POB_PW_ROWS the
+// pairwise kernel's rows per workgroup
 // CU count of the current device (a partitioned MI355X exposes fewer); queried once, no synchronisation involved
 static int cu_count() {
     static int n = 0;
@@ -38,6 +39,7 @@ static bool g_prefetch = getenv("SPH2POB_NO_PREFETCH") == nullptr;
 static int g_pw_rows = getenv("SPH2POB_PW_ROWS") ? atoi(getenv("SPH2POB_PW_ROWS")) : 0;
 static int g_slices_per_wave = getenv("SPH2POB_SLICES_PER_WAVE") ? atoi(getenv("SPH2POB_SLICES_PER_WAVE")) : 0;
 static int g_wgs_per_cu = getenv("SPH2POB_WGS_PER_CU") ? atoi(getenv("SPH2POB_WGS_PER_CU")) : 0;
+static bool g_persistent = getenv("SPH2POB_ALIGNED_KERNEL") != nullptr && getenv("SPH2POB_ALIGNED_KERNEL")[0] == 'p';   // A/B: the persistent form
 
 template <int DIM>
 __device__ __forceinline__ void load_box(const float* __restrict__ p, int64_t i, float (&b)[5]) {
@@ -106,9 +108,21 @@ __device__ unsigned long long* g_stamps = nullptr;
 __device__ __forceinline__ void stamp(int wave_global, int k) {
     if ((threadIdx.x & 63) == 0 && g_stamps) g_stamps[(size_t)wave_global * 8 + k] = __builtin_amdgcn_s_memrealtime();
 }
+// slot 6: where the wave ran (HW_ID | XCC_ID << 32); slot 7: any per-wave figure the caller wants on the timeline
+__device__ __forceinline__ void stamp_where(int wave_global) {
+    const unsigned hw = __builtin_amdgcn_s_getreg(4 | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+    if ((threadIdx.x & 63) == 0 && g_stamps) g_stamps[(size_t)wave_global * 8 + 6] = hw | ((unsigned long long)xcc << 32);
+}
+__device__ __forceinline__ void stamp_value(int wave_global, unsigned long long v) {
+    if ((threadIdx.x & 63) == 0 && g_stamps) g_stamps[(size_t)wave_global * 8 + 7] = v;
+}
 #define SPH_STAMP(k) stamp(wave_global, k)
+#define SPH_STAMP_WHERE() stamp_where(wave_global)
+#define SPH_STAMP_VALUE(v) stamp_value(wave_global, v)
 #else
 #define SPH_STAMP(k)
+#define SPH_STAMP_WHERE()
+#define SPH_STAMP_VALUE(v)
 #endif
 constexpr int kQCap = 128;                    // per-wave stack capacity (<= 63 carried + 64 pushed)
 template <int DIM>
@@ -170,6 +184,7 @@ __global__ __launch_bounds__(kBlock, REF ? 4 : (DIM == 4 ? 7 : 5)) void iou_alig
         else return lean_finish<VARIANT, DIM>(u1, u2, mode, edge);
     };
     SPH_STAMP(0);
+    SPH_STAMP_WHERE();
     // one slice: cull, push the survivors, finish 64 of them when a full wave of records is available
     auto slice = [&](const float (&x)[5], const float (&y)[5], int sl) {
         const int i = sl * 64 + lane;
@@ -216,6 +231,7 @@ __global__ __launch_bounds__(kBlock, REF ? 4 : (DIM == 4 ? 7 : 5)) void iou_alig
     }
     // merge the < 64 leftovers of the four waves and finish them on as few, as full waves as possible
     SPH_STAMP(2);   // loop done
+    SPH_STAMP_VALUE((unsigned long long)count);
     if (lane == 0) leftover[wave] = count;
     __syncthreads();
     SPH_STAMP(3);   // workgroup barrier passed
@@ -232,6 +248,103 @@ __global__ __launch_bounds__(kBlock, REF ? 4 : (DIM == 4 ? 7 : 5)) void iou_alig
         }
     }
     SPH_STAMP(5);   // wave done
+}
+
+// ---- dominant kernel since round 2 (closed-form arithmetic): the one-round chunk form of the same pipeline ----
+// One wave = one chunk of SLICES x 64 consecutive pairs and no carried state: the wave requests its whole chunk up front
+// (the whole input is in flight after the first half microsecond), culls it, compacts the survivors on its own LDS stack
+// (~51 of 128 for the benchmark distribution) and finishes them in ONE pass (a second one when more than 64 survive).
+// No barrier, no merge, 64 VGPRs, so that the 1 954 workgroups of a 1 M-pair launch are all resident at once (8 per CU)
+// and no wave ever runs two finishing passes back to back.  What was measured on MI355X (profiles/r02l_*):
+//   * the SIMDs are saturated from the arrival of the first data to the end: a finishing pass costs a SIMD ~1 500 cycles
+//     = 0.63 us with 8 resident waves (tools/ubench/finish_rate.hip: ~4 cycles per instruction whatever its kind, not
+//     the 2 / 4 / 8 of independent instruction streams), a cull ~190, and the launch takes
+//     ~3.0 us (kernel boundary + first data) + the VALU time; removing the finishing arithmetic leaves 4.5 us, removing
+//     the cull arithmetic saves 0.9 us (r02l_ab_ablation_*.log);
+//   * against the persistent form: 8.8 vs 9.0 us at 1 M pairs, 6.0 vs 6.3 at 500 k, 17.1 vs 18.9 at 2 M, 27.9 vs 30.4
+//     at 4 M, 52.5 vs 54.3 at 8 M, RBFoV 11.8 vs 12.7 at 1 M; bit-identical results (r02l_ab_chunk_*.log) — the
+//     persistent form's leftover merge also ends in partial passes (7 200 passes against 7 813 here, 6 250 if every
+//     pass were full) and puts two passes and a barrier on every wave's critical path;
+//   * pooling the survivors of 4 / 8 / 16 waves in one workgroup-wide stack (one ds_add_rtn per wave, one LDS-only
+//     barrier, chunks assigned or claimed from a counter) so that all passes but one per workgroup are full: 12 % fewer
+//     finishing instructions at 8 waves and NO gain (8.8-8.95 us at 1 M, 55-57 at 8 M; r02l_ab_pool_*.log) — the
+//     barrier couples waves that sit on different SIMDs; built, measured, removed;
+//   * rotating which wave of the persistent form takes which leftover chunk: the hardware already rotates the
+//     wave -> SIMD placement from workgroup to workgroup (tools/ubench/hwid.hip); +0.3 us, removed.
+template <int DIM, int SLICES>
+struct ChunkQueue {
+    float f[2 * DIM][64 * SLICES];
+    int idx[64 * SLICES];
+};
+constexpr int kChunkSlices = 2;
+template <int VARIANT, int DIM, bool ARC, int SLICES>
+__global__ __launch_bounds__(kBlock, DIM == 4 ? 8 : 7) void iou_aligned_chunk_kernel(const float* __restrict__ b1, const float* __restrict__ b2,
+                                                                      float* __restrict__ out, int n, int mode, int edge_arg) {
+    __shared__ ChunkQueue<DIM, SLICES> queues[kBlock / 64];
+    const int edge = ARC ? (int)EDGE_ARC : (edge_arg & 0xff);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    ChunkQueue<DIM, SLICES>& q = queues[wave];
+    const int base = (blockIdx.x * (kBlock / 64) + wave) * (64 * SLICES);
+    if (base >= n) return;   // wave-uniform; the kernel has no barrier
+    const int wave_global = blockIdx.x * (kBlock / 64) + wave;
+    (void)wave_global;
+    SPH_STAMP(0);
+    SPH_STAMP_WHERE();
+#if defined(SPH_STAMPS)
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
+#endif
+    float x[SLICES][5], y[SLICES][5];
+#pragma unroll
+    for (int s = 0; s < SLICES; s++) {
+        const int i = base + s * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 5; k++) { x[s][k] = 0.0f; y[s][k] = 0.0f; }
+        if (i < n) { load_box<DIM>(b1, i, x[s]); load_box<DIM>(b2, i, y[s]); }
+    }
+    int count = 0;
+#pragma unroll
+    for (int s = 0; s < SLICES; s++) {
+        const int i = base + s * 64 + lane;
+        bool surv = false;
+        if (i < n) {
+#if defined(SPH_ABL_NOCULL)
+            if (((lane * 2654435761u + s * 40503u + blockIdx.x) >> 7) % 5 >= 2) out[i] = x[s][0] + y[s][0] > 1e30f ? 1.0f : 0.0f;   // ABLATION: 40 % survive, no cull arithmetic
+#else
+            if (fast_cull<DIM, VARIANT == VARIANT_LEGACY>(x[s], y[s], edge)) out[i] = 0.0f;
+#endif
+            else surv = true;
+        }
+        const unsigned long long m = __ballot(surv);
+        if (surv) {
+            const int slot = count + __popcll(m & ((1ull << lane) - 1ull));
+#pragma unroll
+            for (int k = 0; k < DIM; k++) { q.f[k][slot] = x[s][k]; q.f[DIM + k][slot] = y[s][k]; }
+            q.idx[slot] = i;
+        }
+        count += __popcll(m);
+        if (s == 0) SPH_STAMP(1);
+    }
+    SPH_STAMP(2);
+    SPH_STAMP(3);
+    SPH_STAMP_VALUE((unsigned long long)count);
+    wave_lds_fence();
+    for (int b = 0; b < count; b += 64) {
+        const int slot = b + lane;
+        if (slot < count) {
+            float u1[5], u2[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) { u1[k] = k < DIM ? q.f[k][slot] : 0.0f; u2[k] = k < DIM ? q.f[DIM + k][slot] : 0.0f; }
+#if defined(SPH_ABL_NOFINISH)
+            out[q.idx[slot]] = u1[0] + u2[1] + u1[2] + u2[3] > 1e30f ? 1.0f : 0.5f;   // ABLATION: no finishing arithmetic
+#else
+            out[q.idx[slot]] = lean_finish<VARIANT, DIM>(u1, u2, mode, edge);
+#endif
+        }
+    }
+    SPH_STAMP(5);
+#if defined(SPH_STAMPS)
+    if (lane == 0 && g_stamps) g_stamps[(size_t)wave_global * 8 + 4] = __builtin_amdgcn_s_memtime() - clk0;   // shader clocks of the wave's life
+#endif
 }
 
 // ---- pairwise IoU for the assigner call pattern (few rows x many columns), closed-form core ----
@@ -922,7 +1035,7 @@ struct AlignedLaunch {
     const float *b1, *b2; float* out; int64_t n; int mode, edge, angle; hipStream_t s; bool fast = true;
     template <int V, int D> int run() {
         dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-        if (V <= 2 && n < ((int64_t)1 << 31) - 64 && !g_no_compact) {
+        if (V <= 2 && n < ((int64_t)1 << 31) - 1024 && !g_no_compact) {
             // persistent-style grid.  Measured on MI355X (tools/sweep_slices.sh): every CU must hold the same number of
             // workgroups (1 303 workgroups = 5.09 per CU take 12 % longer than 1 536 = 6 per CU); 6 per CU (24 waves per CU)
             // is the best or within noise of the best from 125 k to 8 M pairs; small launches want one slice per wave
@@ -941,6 +1054,11 @@ struct AlignedLaunch {
             const bool ref_finish = !fast || V == 2 || angle != SPH2POB_ANGLE_EQUATOR;
             const int edge_k = edge | (angle << 8);
 #define SPH_PIPE(PF, ARC, REF) hipLaunchKernelGGL((iou_aligned_compact_kernel<VV, D, PF, ARC, REF>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge_k)
+            if (!ref_finish && V < 2 && !g_persistent) {   // the default: one-round chunk kernel
+                const unsigned cw = (unsigned)((n + kBlock * kChunkSlices - 1) / (kBlock * kChunkSlices));
+                if (edge == SPH2POB_EDGE_ARC) hipLaunchKernelGGL((iou_aligned_chunk_kernel<VV, D, true, kChunkSlices>), dim3(cw), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge_k);
+                else hipLaunchKernelGGL((iou_aligned_chunk_kernel<VV, D, false, kChunkSlices>), dim3(cw), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge_k);
+            } else
             if (ref_finish) { if (wgs > kCUs * 4) wgs = kCUs * 4; SPH_PIPE(true, false, true); }   // reference-order finish: 4 waves per SIMD
             else if (edge == SPH2POB_EDGE_ARC) { if (g_prefetch) SPH_PIPE(true, true, false); else SPH_PIPE(false, true, false); }
             else { if (g_prefetch) SPH_PIPE(true, false, false); else SPH_PIPE(false, false, false); }
