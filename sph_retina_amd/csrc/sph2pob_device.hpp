@@ -63,11 +63,20 @@ SPH_DEV float min_nan(float a, float b) { return __builtin_elementwise_minimum(a
 SPH_DEV float max_nan(float a, float b) { return __builtin_elementwise_maximum(a, b); }
 // NaN iff any coordinate of the pair is NaN (+-inf stays inf: the reference's clamps make it finite; an infinite gamma,
 // which the reference never clamps for bboxes1 and whose sine is NaN, counts as NaN)
+// the NaN-propagating maximum of the pair's coordinates: NaN iff any of them is (a chain of three-input maxima: four
+// v_maximum3_f32 for the eight coordinates of a BFoV pair)
+template <int DIM>
+SPH_DEV float pair_nan_carrier(const float (&a)[5], const float (&b)[5]) {
+    float m = max_nan(max_nan(a[0], a[1]), a[2]);
+    m = max_nan(max_nan(m, a[3]), b[0]);
+    m = max_nan(max_nan(m, b[1]), b[2]);
+    m = max_nan(m, b[3]);
+    if (DIM == 5) m = max_nan(max_nan(m, a[4] - a[4]), b[4] - b[4]);   // inf - inf = NaN
+    return m;
+}
 template <int DIM>
 SPH_DEV bool pair_has_nan(const float (&a)[5], const float (&b)[5]) {
-    float m = max_nan(max_nan(a[0], a[1]), max_nan(a[2], a[3]));
-    m = max_nan(m, max_nan(max_nan(b[0], b[1]), max_nan(b[2], b[3])));
-    if (DIM == 5) m = max_nan(m, max_nan(a[4] - a[4], b[4] - b[4]));   // inf - inf = NaN
+    const float m = pair_nan_carrier<DIM>(a, b);
     return m != m;
 }
 

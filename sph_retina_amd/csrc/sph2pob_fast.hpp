@@ -24,6 +24,11 @@
 
 namespace sph2pob {
 
+SPH_DEV unsigned float_bits(float x) { return __builtin_bit_cast(unsigned, x); }
+SPH_DEV unsigned max3_u32(unsigned a, unsigned b, unsigned c) {
+    const unsigned m = a > b ? a : b;
+    return m > c ? m : c;   // one v_max3_u32
+}
 SPH_DEV float fast_rcp(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_rcpf(x);
@@ -139,6 +144,18 @@ SPH_DEV float atan2_r(float y, float x) {
     p = ay > ax ? 1.57079632679489662f - p : p;
     p = x < 0.0f ? 3.14159265358979324f - p : p;
     return y < 0.0f ? -p : p;
+}
+
+// atan2(y, x) for y >= 0 and x^2 + y^2 ~ 1 (the angle between two unit vectors from |cross| and dot): the same
+// quotient, polynomial and octant fix-ups as atan2_r without the selects that cannot fire on that domain
+// (the 0 / 0 guard, the clamp of the quotient at 1 — min / max <= 1 up to one rounding of the product — and y < 0)
+SPH_DEV float atan2_pos(float y, float x) {
+    const float ax = fabsf(x);
+    const float mx = fmaxf(ax, y), mn = fminf(ax, y);
+    const float t = mn * fast_rcp(mx);
+    float p = atan_unit(t);
+    p = y > ax ? 1.57079632679489662f - p : p;
+    return x < 0.0f ? 3.14159265358979324f - p : p;
 }
 
 constexpr float kMinAng = 4.8828125e-4f;     // acos(float(1 - 1e-7))
@@ -287,26 +304,47 @@ SPH_DEV bool cull_pair(const CullBox& g, const CullBox& p) {
 template <int DIM, bool CHORD = false>
 SPH_DEV bool fast_cull(const float (&g)[5], const float (&p)[5], int edge) {
 #pragma clang fp contract(fast)
-    // scale first, clamp second: the product is a canonical number, so the compiler does not have to quiet a possible
-    // signalling NaN of the loaded value (v_max x, x) in front of every v_min / v_max; same values (monotone rounding)
-    const float kPiHi = 180.0f * kDeg2Rad;
-    // NaN-propagating clamps: any NaN coordinate ends in R2 or C and makes the final comparison false (not culled)
-    float wg = min_nan(g[2] * kDeg2Rad, kPiHi), hg = min_nan(g[3] * kDeg2Rad, kPiHi);
-    float wp = min_nan(p[2] * kDeg2Rad, kPiHi), hp = min_nan(p[3] * kDeg2Rad, kPiHi);
-    if (edge != EDGE_ARC) { wg = edge_length(wg, edge); hg = edge_length(hg, edge); wp = edge_length(wp, edge); hp = edge_length(hp, edge); }
-    const float dg = wg * wg + hg * hg, dp = wp * wp + hp * hp, prod = dg * dp;
-    const float R2 = 0.25f * (dg + dp) + 0.5f * (prod * fast_rsq(prod)) + 9.01e-3f;
-    const float cosR_lb = fmaf(fmaf(fmaf(-1.0f / 720.0f, R2, 1.0f / 24.0f), R2, -0.5f), R2, 1.0f);
+    // Every coordinate inside the range the spherical jitter clamps it to (theta in [0, 360], phi and the extents in
+    // [0, 180] degrees)?  Tested on the bit patterns as unsigned integers — for non-negative floats the order of the
+    // patterns is the order of the values, and a negative number, an infinity or a NaN has a pattern above that of any
+    // bound — with 2 v_max3_u32 + 2 v_max_u32 + 2 compares for the eight coordinates.  A pair with a coordinate out of
+    // range (or NaN) is never culled: the finishing stage clamps it exactly like the reference does.  (Round 1 clamped
+    // all eight values here instead, NaN-propagating: 12 v_minimum3 / v_maximum3.)
+    const unsigned mg = max3_u32(float_bits(g[1]), float_bits(g[2]), float_bits(g[3]));
+    const unsigned mp = max3_u32(float_bits(p[1]), float_bits(p[2]), float_bits(p[3]));
+    const unsigned mth = float_bits(g[0]) > float_bits(p[0]) ? float_bits(g[0]) : float_bits(p[0]);
+    const bool in_range = ((mg > mp ? mg : mp) <= 0x43340000u) & (mth <= 0x43b40000u);   // 180.0f, 360.0f
+    // (r_g + r_p)^2 with r = half the diagonal: (d_g + d_p + 2 sqrt(d_g d_p)) / 4, d = w^2 + h^2.  For arc edges the
+    // degrees -> radians factor is folded into the last FMA; a degenerate box (d = 0) gives 0 * inf = NaN: never culled.
+    float dg, dp, quarter;
+    if (edge == EDGE_ARC) {
+        dg = fmaf(g[2], g[2], g[3] * g[3]);
+        dp = fmaf(p[2], p[2], p[3] * p[3]);
+        quarter = 0.25f * kDeg2Rad * kDeg2Rad;
+    } else {
+        const float wg = edge_length(g[2] * kDeg2Rad, edge), hg = edge_length(g[3] * kDeg2Rad, edge);
+        const float wp = edge_length(p[2] * kDeg2Rad, edge), hp = edge_length(p[3] * kDeg2Rad, edge);
+        dg = fmaf(wg, wg, hg * hg);
+        dp = fmaf(wp, wp, hp * hp);
+        quarter = 0.25f;
+    }
+    const float prod = dg * dp;
+    // + 9.01e-3: the 1.5e-3 rad margin (both jitters + the reference's rounding of A) moved into R^2 (header comment)
+    const float R2 = fmaf(quarter, fmaf(2.0f, prod * fast_rsq(prod), dg + dp), 9.01e-3f);
+    // 2 cos(angular distance) = cos(phi_g - phi_p) (1 + cos dtheta) + cos(phi_g + phi_p) (1 - cos dtheta)
     const float kRev = 1.0f / 360.0f;
-    // latitudes / longitudes in revolutions, clamped like the jitter clamps them (phi to [0, 180], theta to [0, 360] deg)
-    const float phg = min_nan(max_nan(g[1] * kRev, 0.0f), 0.5f), php = min_nan(max_nan(p[1] * kRev, 0.0f), 0.5f);
-    const float thg = min_nan(max_nan(g[0] * kRev, 0.0f), 1.0f), thp = min_nan(max_nan(p[0] * kRev, 0.0f), 1.0f);
-    const float u = hw_cos_rev(phg - php), v = hw_cos_rev(phg + php);
-    const float cD = hw_cos_rev(thp - thg);
-    float C = 0.5f * ((u + v) + (u - v) * cD);
-    if (DIM == 5) C = fmaf(g[4] + p[4], 0.0f, C);   // a NaN / infinite gamma must not be culled either
-    if (CHORD) return (R2 < 3.9f) & (C < fmaf(-0.5f, R2, 1.0f) - 1e-4f);
-    return (R2 < 8.9f) & (C < cosR_lb - 1e-4f);
+    const float ag = g[1] * kRev;
+    const float u = hw_cos_rev(fmaf(p[1], -kRev, ag)), v = hw_cos_rev(fmaf(p[1], kRev, ag));
+    const float cD = hw_cos_rev((p[0] - g[0]) * kRev);
+    float C2 = fmaf(u - v, cD, u + v);
+    if (DIM == 5) C2 = fmaf(g[4] + p[4], 0.0f, C2);   // a NaN / infinite gamma must not be culled either
+    // against twice the lower bound of cos R (1 - R^2/2 + R^4/24 - R^6/720 <= cos R), less 1e-4 for the hardware trig.
+    // The bound decreases in R^2 on the whole axis (its derivative -1/2 + x/12 - x^2/240 has no real root) and is below
+    // -1.12 from R^2 = 8.9 on, where 2 cos >= -2 (1 + 3e-6) can never be below twice it: no separate test of R.
+    // CHORD (sph2pob_legacy): cos L < 1 - R^2/2, which is below -1 from R^2 = 4 on
+    const float bound2 = CHORD ? (2.0f - 2e-4f) - R2
+                               : fmaf(fmaf(fmaf(-1.0f / 360.0f, R2, 1.0f / 12.0f), R2, -1.0f), R2, 2.0f - 2e-4f);
+    return in_range & (C2 < bound2);
 }
 
 // trig by-products of stage 1 that the loss adjoint reuses
@@ -324,7 +362,9 @@ struct PlanarPair {
 // lanes needs a branch skips its code with one scalar branch instead of executing it under an empty mask or paying
 // for always-on selects.  On the host (unit tests) a "wave" is one pair.
 #if defined(__HIP_DEVICE_COMPILE__)
-#define SPH_ANY_LANE(cond) (__ballot(cond) != 0ull)
+// (Hand it ONE compare where possible and combine guards with ||: the mask of a single v_cmp is the ballot, whereas a
+// condition built from several compares is first turned into 0 / 1 per lane and compared again, two more VALU instructions.)
+#define SPH_ANY_LANE(cond) (__builtin_amdgcn_ballot_w64(cond) != 0ull)
 #else
 #define SPH_ANY_LANE(cond) (cond)
 #endif
@@ -374,7 +414,7 @@ SPH_DEV void lean_front(const float (&x1)[5], const float (&x2)[5], int edge, Pl
     // ---- planar boxes as (cos, sin) ----
     const float S2 = fmaf(N, N, D * D);
     const float iS = fast_rsq(S2);
-    float A = atan2_r(S2 * iS, C);
+    float A = atan2_pos(S2 * iS, C);
     const float Amin = VARIANT == VARIANT_STANDARD ? 2.0f * kMinAng : kMinAng;
     if (GATES) o.g_A = A > Amin;
     A = fmaxf(A, Amin);
@@ -384,13 +424,16 @@ SPH_DEV void lean_front(const float (&x1)[5], const float (&x2)[5], int edge, Pl
         // not differences, so they stay meaningful down to ~1e-15 (e.g. two boxes clamped onto a pole: A ~ 1e-7 but
         // the bearings still differ by the longitude difference); only a literal zero needs a convention: a = pi/2.
         if (!(S2 > 1e-30f)) { ca = 0.0f; sa = 1.0f; cb = 0.0f; sb = 1.0f; }
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("");   // keeps this a skipped block: if-converted it costs every pass four v_mov under an empty mask
+#endif
     }
     float ga = 0.0f, gb = 0.0f;
     // the reference's sign * |acos(clamp(cos a))| floors |a| and |pi - a| at kMinAng (angle_floor)
     auto floors = [&]() {
         const bool fa = fabsf(sa) < kMinAng, fb = fabsf(sb) < kMinAng;
         if (GATES) { o.g_ag = !fa; o.g_ap = !fb; }
-        if (SPH_ANY_LANE(fa | fb)) { angle_floor(ca, sa); angle_floor(cb, sb); }
+        if (SPH_ANY_LANE(fa) || SPH_ANY_LANE(fb)) { angle_floor(ca, sa); angle_floor(cb, sb); }   // (see SPH_ANY_LANE)
     };
     if (DIM == 5) {
         ga = x1[4] * kDeg2Rad;
@@ -408,10 +451,12 @@ SPH_DEV void lean_front(const float (&x1)[5], const float (&x2)[5], int edge, Pl
     // ---- rotated jitter (sph_iou_api.py:222-242) on (x, w, h, a); its decisions need real angles only when the two
     // angles are within ~1.8e-3 of each other modulo 2 pi ----
     float c = fmaf(ca, cb, sa * sb), s = fmaf(sa, cb, -(ca * sb));  // cos / sin of (a_g - a_p)
-    bool sim = (A < e) | (fabsf(wg - wp) < e) | (fabsf(hg - hp) < e);
+    const bool sim_dist = A < e, sim_size = fminf(fabsf(wg - wp), fabsf(hg - hp)) < e;
+    bool sim = sim_dist | sim_size;
     bool close = false;
-    const bool cand = (c > 0.5f) & (fabsf(s) < 2.0e-3f);
-    if (SPH_ANY_LANE(cand)) {
+    bool any_sim_close = SPH_ANY_LANE(sim_dist) || SPH_ANY_LANE(sim_size);   // wave-uniform
+    const bool cand_s = fabsf(s) < 2.0e-3f, cand = (c > 0.5f) & cand_s;
+    if (SPH_ANY_LANE(cand_s)) {   // (the wave-level guard on the sine alone: a single compare's mask, see SPH_ANY_LANE)
         if (cand) {
             float a1, a2;
             if (DIM == 5 && VARIANT == VARIANT_EFFICIENT) {  // a = floor(atan2(N, D)) - gamma, not wrapped
@@ -429,9 +474,10 @@ SPH_DEV void lean_front(const float (&x1)[5], const float (&x2)[5], int edge, Pl
             if (sim) { a1 += e; a2 += (float)(5 * kEpsS); }
             close = fabsf(a1 - a2) < ea;
         }
+        any_sim_close = any_sim_close || SPH_ANY_LANE(sim | close);
     }
     float dx = A, dy = 0.0f;
-    if (SPH_ANY_LANE(sim | close)) {   // constant rotations of (cos, sin) instead of new trig
+    if (any_sim_close) {   // constant rotations of (cos, sin) instead of new trig
         if (sim) {
             dx += e; dy += e;  // (x, y) += (e, e) vs (2e, 2e)
             wg += (float)(2 * kEpsS); hg += (float)(2 * kEpsS); wp += e; hp += e;
@@ -451,8 +497,9 @@ SPH_DEV void lean_front(const float (&x1)[5], const float (&x2)[5], int edge, Pl
         o.g_wg = wg >= (float)(2 * kEpsA / 10); o.g_hg = hg >= (float)(2 * kEpsA / 10);
         o.g_wp = wp >= (float)(kEpsA / 10);     o.g_hp = hp >= (float)(kEpsA / 10);
     }
-    wg = fmaxf(wg, (float)(2 * kEpsA / 10)); hg = fmaxf(hg, (float)(2 * kEpsA / 10));
-    wp = fmaxf(wp, (float)(kEpsA / 10));     hp = fmaxf(hp, (float)(kEpsA / 10));
+    // (one v_med3 each: fmaxf on a value that reaches here through a guarded block costs a v_max x, x in front of it)
+    wg = clampf(wg, (float)(2 * kEpsA / 10), 3.0e38f); hg = clampf(hg, (float)(2 * kEpsA / 10), 3.0e38f);
+    wp = clampf(wp, (float)(kEpsA / 10), 3.0e38f);     hp = clampf(hp, (float)(kEpsA / 10), 3.0e38f);
     if (DIM == 5) {
         const bool wide = (fabsf(ga) > 3.1f) | (fabsf(gb) > 3.1f);
         if (SPH_ANY_LANE(wide)) {
@@ -486,7 +533,12 @@ SPH_DEV void lean_front(const float (&x1)[5], const float (&x2)[5], int edge, Pl
 template <int VARIANT, int DIM>
 SPH_DEV float lean_finish(const float (&in1)[5], const float (&in2)[5], int mode, int edge) {
     const float e = (float)kEpsS, e2 = (float)(2 * kEpsS);
-    const bool bad = pair_has_nan<DIM>(in1, in2);
+    // evaluated HERE, not where it is used: left to the scheduler the test sinks to the end of the pass and keeps the
+    // eight raw coordinates alive (and copied) through all of it
+    float carrier = pair_nan_carrier<DIM>(in1, in2);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(carrier));
+#endif
     // ---- jitter_spherical (sph_iou_api.py:244-260): shift only where `similar`, clamps always ----
     float x1[5], x2[5];
     bool similar = false;
@@ -518,17 +570,19 @@ SPH_DEV float lean_finish(const float (&in1)[5], const float (&in2)[5], int mode
     const float pbx = fmaf(q.dx, q.ca, q.dy * q.sa), pby = fmaf(q.dy, q.ca, -(q.dx * q.sa));
     float t2 = edges_inside3(pax, pay, q.c, q.s, ic, is, aic, ais, hwa, hha, hwb, hhb, q.wg, q.hg, true) +
                edges_inside3(pbx, pby, q.c, -q.s, ic, -is, aic, ais, hwb, hhb, hwa, hha, q.wp, q.hp, false);
-    const bool near = fminf(fabsf(q.s), fabsf(q.c)) < kNearParallel;   // the two jitter steps cancelled: DESIGN.md §9
-    if (SPH_ANY_LANE(near)) {
-        if (near) t2 = 2.0f * near_parallel_inter(pax, pay, q.c, q.s, hwa, hha, hwb, hhb);
+    // the two jitter steps cancelled: DESIGN.md §9.  (Two compares and a scalar OR of their masks; written as one
+    // condition the compiler turns them into abs / canonicalise / min / compare: five VALU instructions)
+    const bool near_s = fabsf(q.s) < kNearParallel, near_c = fabsf(q.c) < kNearParallel;
+    if (SPH_ANY_LANE(near_s) || SPH_ANY_LANE(near_c)) {
+        if (near_s | near_c) t2 = 2.0f * near_parallel_inter(pax, pay, q.c, q.s, hwa, hha, hwb, hhb);
     }
-    const float inter = 0.5f * fmaxf(t2, 0.0f);
+    const float inter = 0.5f * clampf(t2, 0.0f, 3.0e38f);
     const float a1 = q.wg * q.hg, a2 = q.wp * q.hp;
     const float base = mode == MODE_IOU ? (a1 + a2 - inter) : a1;
     float rb = fast_rcp(base);
     rb = rb * fmaf(-base, rb, 2.0f);  // one Newton step: ~0.5 ulp quotient without the IEEE divide expansion
     const float iou = fminf(fmaxf(inter * rb, 0.0f), 1.0f);
-    return bad ? __builtin_nanf("") : iou;
+    return carrier != carrier ? __builtin_nanf("") : iou;
 }
 
 // VARIANT: 0 standard, 1 efficient.  Returns clamp(IoU, 0, 1) of one pair (one-lane-per-pair kernels, NMS rows, host

@@ -144,6 +144,11 @@ __device__ __forceinline__ int queue_load(const WaveQueue<DIM>& q, int slot, flo
     for (int k = 0; k < 5; k++) { j1[k] = k < DIM ? q.f[k][slot] : 0.0f; j2[k] = k < DIM ? q.f[DIM + k][slot] : 0.0f; }
     return q.idx[slot];
 }
+// number of set bits of a wave mask below this lane: v_mbcnt_lo + v_mbcnt_hi (the 64-bit shift / and / popcount form
+// costs eight instructions)
+__device__ __forceinline__ int rank_below(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -193,8 +198,8 @@ __global__ __launch_bounds__(kBlock, REF ? 4 : (DIM == 4 ? 7 : 5)) void iou_alig
             if (fast_cull<DIM, VARIANT == VARIANT_LEGACY>(x, y, edge)) out[i] = 0.0f;
             else surv = true;
         }
-        const unsigned long long m = __ballot(surv);
-        if (surv) queue_store<DIM>(q, count + __popcll(m & ((1ull << lane) - 1ull)), x, y, i);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(surv);
+        if (surv) queue_store<DIM>(q, count + rank_below(m), x, y, i);
         count += __popcll(m);
         if (sl == wave_global) SPH_STAMP(1);   // first slice culled: its data has arrived
         if (count >= 64) {  // wave-uniform
@@ -305,18 +310,17 @@ __global__ __launch_bounds__(kBlock, DIM == 4 ? 8 : 7) void iou_aligned_chunk_ke
 #pragma unroll
     for (int s = 0; s < SLICES; s++) {
         const int i = base + s * 64 + lane;
-        bool surv = false;
-        if (i < n) {
+        // (lanes past the end hold zero boxes: degenerate, never culled; masks combined as masks, not through a bool)
 #if defined(SPH_ABL_NOCULL)
-            if (((lane * 2654435761u + s * 40503u + blockIdx.x) >> 7) % 5 >= 2) out[i] = x[s][0] + y[s][0] > 1e30f ? 1.0f : 0.0f;   // ABLATION: 40 % survive, no cull arithmetic
+        const bool culled = ((lane * 2654435761u + s * 40503u + blockIdx.x) >> 7) % 5 >= 2;   // ABLATION: 40 % survive, no cull arithmetic
 #else
-            if (fast_cull<DIM, VARIANT == VARIANT_LEGACY>(x[s], y[s], edge)) out[i] = 0.0f;
+        const bool culled = fast_cull<DIM, VARIANT == VARIANT_LEGACY>(x[s], y[s], edge);
 #endif
-            else surv = true;
-        }
-        const unsigned long long m = __ballot(surv);
+        const bool inside = i < n, surv = inside & !culled;
+        if (inside & culled) out[i] = 0.0f;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(surv);
         if (surv) {
-            const int slot = count + __popcll(m & ((1ull << lane) - 1ull));
+            const int slot = count + rank_below(m);
 #pragma unroll
             for (int k = 0; k < DIM; k++) { q.f[k][slot] = x[s][k]; q.f[DIM + k][slot] = y[s][k]; }
             q.idx[slot] = i;
@@ -393,8 +397,8 @@ __global__ __launch_bounds__(kBlock) void iou_pairwise_compact_kernel(const floa
             if (cull_pair(CullBox{rc.x, rc.y, rc.z, rc.w}, ca)) out[(int64_t)(r0 + i) * n + j] = 0.0f;
             else surv = true;
         }
-        const unsigned long long mk = __ballot(surv);
-        if (surv) st[count + __popcll(mk & ((1ull << lane) - 1ull))] = make_int2(i, j);
+        const unsigned long long mk = __builtin_amdgcn_ballot_w64(surv);
+        if (surv) st[count + rank_below(mk)] = make_int2(i, j);
         count += __popcll(mk);
         if (count >= 64) {
             count -= 64;
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(kBlock) void loss_fwd_kernel(const float* __restric
     const float w = scale * element_weight<DIM>(weight, wd, i);
     // dense heads pass every anchor with weight 0 on the negatives (sph_retina_head.py:261-264): a wave whose 64
     // weights are all zero writes its zeros and leaves (loss * 0 == 0 for every finite loss)
-    if (!iou && __ballot(w != 0.0f) == 0) {
+    if (!iou && __builtin_amdgcn_ballot_w64(w != 0.0f) == 0) {
         loss[i] = 0.0f;
         return;
     }
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(kBlock) void loss_fwd_sum_kernel(const float* __res
     float v = 0.0f;
     const bool live = i < n;
     const float w = live ? element_weight<DIM>(weight, wd, i) : 0.0f;
-    if (__ballot(w != 0.0f) != 0) {   // an all-zero-weight wave contributes exact zeros (see loss_fwd_kernel)
+    if (__builtin_amdgcn_ballot_w64(w != 0.0f) != 0) {   // an all-zero-weight wave contributes exact zeros (see loss_fwd_kernel)
         if (live) {
             float x[5], y[5], gx[5], gy[5];
             load_box<DIM>(pred, i, x);
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(kBlock) void loss_bwd_kernel(const float* __restric
     if (i >= n) return;
     float x[5], y[5], gx[5], gy[5];
     float g = grad_out[i * grad_stride] * scale * element_weight<DIM>(weight, wd, i);
-    if (__ballot(g != 0.0f) == 0) {  // all-negative wave (see loss_fwd_kernel): zero gradients, no geometry
+    if (__builtin_amdgcn_ballot_w64(g != 0.0f) == 0) {  // all-negative wave (see loss_fwd_kernel): zero gradients, no geometry
 #pragma unroll
         for (int k = 0; k < 5; k++) gx[k] = gy[k] = 0.0f;
     } else {
@@ -561,7 +565,7 @@ __global__ __launch_bounds__(kBlock) void loss_fwd_grad_kernel(const float* __re
     float x[5], y[5], gx[5], gy[5], l = 0.0f;
 #pragma unroll
     for (int k = 0; k < 5; k++) gx[k] = gy[k] = 0.0f;
-    if (__ballot(w != 0.0f) != 0) {   // an all-zero-weight wave: zero loss, zero gradients, no geometry
+    if (__builtin_amdgcn_ballot_w64(w != 0.0f) != 0) {   // an all-zero-weight wave: zero loss, zero gradients, no geometry
         if (live) {
             load_box<DIM>(pred, i, x);
             load_box<DIM>(target, i, y);
@@ -681,7 +685,7 @@ __global__ __launch_bounds__(kBlock) void nms_mask_kernel(const float* __restric
             load_box<DIM>(boxes, j, y);
             hit = pair_iou_sel<VARIANT, DIM, FAST>(x, y, MODE_IOU, EDGE_ARC, ANGLE_EQUATOR) > thr;
         }
-        unsigned long long bits = __ballot(hit);
+        unsigned long long bits = __builtin_amdgcn_ballot_w64(hit);
         if (lane == 0) row[r] = bits;
     }
 }
@@ -749,8 +753,8 @@ __global__ __launch_bounds__(kBlock) void nms_mask_compact_kernel(const float* _
                 load_box<DIM>(boxes, j, y);
                 surv = !cull_pair(cx, cull_box(y, EDGE_ARC));
             }
-            const unsigned long long m = __ballot(surv);
-            if (surv) st[count + __popcll(m & ((1ull << lane) - 1ull))] = (int)j;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(surv);
+            if (surv) st[count + rank_below(m)] = (int)j;
             count += __popcll(m);
             if (count >= 64) {
                 count -= 64;
@@ -810,7 +814,7 @@ __global__ __launch_bounds__(kBlock) void nms_sweep_kernel(const unsigned long l
                 const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
                 // scalar (SGPR) state of the serial chain; rows of the block outside this segment start out "removed"
                 // (the readlane builtins return int: cast before widening, or bit 31 sign-extends)
-                unsigned long long rem = removed[b] | ~__ballot(mine);
+                unsigned long long rem = removed[b] | ~__builtin_amdgcn_ballot_w64(mine);
                 rem = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(rem >> 32)) << 32) |
                       (unsigned)__builtin_amdgcn_readfirstlane((unsigned)rem);
                 unsigned long long keepbits = 0ull;
