@@ -361,10 +361,20 @@ struct PlanarPair {
 // "any lane of the wave": the rare branches of the finishing stage are guarded wave-uniformly, so a wave none of whose
 // lanes needs a branch skips its code with one scalar branch instead of executing it under an empty mask or paying
 // for always-on selects.  On the host (unit tests) a "wave" is one pair.
-#if defined(__HIP_DEVICE_COMPILE__)
+// What the guards cost (tools/ubench/finish_rate.hip, 8 resident waves per SIMD, survivors of the benchmark distribution:
+// profiles/r02n_finish_rate*.log): 531 ns per pass per SIMD with them, 402 ns for the same arithmetic with every guarded
+// block compiled out — each guard ends a basic block at a branch that waits for a VALU compare.  The alternatives cost
+// more: always-on selects (round 1), and a straight-line common path that flags rare lanes and ends in ONE guard in front
+// of a re-evaluation by this general form: 0.72 % of the survivors are rare (0.63 % alone have planar angles within
+// 2e-3 of each other: the bearings of a pair are correlated), i.e. 31 % of the 51-lane passes would run twice — built
+// and measured: 10.4 us against 8.4 us per 1 M pairs (profiles/r02o_ab_two_tier_*.log).
+#if defined(SPH_ANY_LANE)
+// (a microbenchmark's own definition: tools/ubench/finish_rate.hip -DNO_GUARDS prices the guards)
+#elif defined(__HIP_DEVICE_COMPILE__)
 // (Hand it ONE compare where possible and combine guards with ||: the mask of a single v_cmp is the ballot, whereas a
-// condition built from several compares is first turned into 0 / 1 per lane and compared again, two more VALU instructions.)
-#define SPH_ANY_LANE(cond) (__builtin_amdgcn_ballot_w64(cond) != 0ull)
+// condition built from several compares is first turned into 0 / 1 per lane and compared again, two more VALU
+// instructions.  __builtin_expect: the rare blocks are laid out behind the loop, the common path falls through.)
+#define SPH_ANY_LANE(cond) __builtin_expect(__builtin_amdgcn_ballot_w64(cond) != 0ull, 0)
 #else
 #define SPH_ANY_LANE(cond) (cond)
 #endif

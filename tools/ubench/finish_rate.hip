@@ -5,6 +5,9 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>
+#if defined(NO_GUARDS)
+#define SPH_ANY_LANE(cond) false   // the common path alone: what the wave-uniform guards of the rare branches cost
+#endif
 #include "../../sph_retina_amd/csrc/sph2pob_fast.hpp"
 using namespace sph2pob;
 
@@ -22,7 +25,10 @@ __global__ __launch_bounds__(256, 8) void k(const float* __restrict__ b1, const 
         if (WHAT == 0) r = lean_finish<0, 4>(x, y, 0, 0);
         else r = fast_cull<4>(x, y, 0) ? 1.0f : 0.0f;
         acc += r;
-        x[0] += r * 1e-3f + 1e-3f;   // the next pass depends on this one
+        // the next pass depends on this one, through every coordinate (nothing of the pass is loop-invariant)
+        const float d = r * 1e-4f + 1e-4f;
+        x[0] += d; x[1] -= 0.5f * d; x[2] += 0.25f * d; x[3] -= 0.125f * d;
+        y[0] -= 0.3f * d; y[1] += 0.2f * d; y[2] -= 0.1f * d; y[3] += 0.05f * d;
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     out[i] = acc;
@@ -33,13 +39,18 @@ int main() {
     const int maxwg = 256 * 8, n = maxwg * 256;
     std::vector<float> h1(n * 4), h2(n * 4);
     srand(1);
-    for (int i = 0; i < n; i++) {
-        // overlapping pairs (the survivors of the cull): second box near the first
-        float th = rand() / (float)RAND_MAX * 300 + 20, ph = rand() / (float)RAND_MAX * 140 + 20;
-        float a = rand() / (float)RAND_MAX * 60 + 5, b = rand() / (float)RAND_MAX * 60 + 5;
-        h1[i * 4] = th; h1[i * 4 + 1] = ph; h1[i * 4 + 2] = a; h1[i * 4 + 3] = b;
-        h2[i * 4] = th + rand() / (float)RAND_MAX * 10 - 5; h2[i * 4 + 1] = ph + rand() / (float)RAND_MAX * 10 - 5;
-        h2[i * 4 + 2] = a * (0.7f + 0.6f * rand() / (float)RAND_MAX); h2[i * 4 + 3] = b * (0.7f + 0.6f * rand() / (float)RAND_MAX);
+    // survivors of the cull on the benchmark distribution (bench.py make_boxes: theta 360 u, phi 180 u, extents 1 + 99 u):
+    // what the finishing pass sees in the dominant launch, rare branches at their real frequencies
+    {
+        auto uni = []() { return rand() / (float)RAND_MAX; };
+        int i = 0;
+        while (i < n) {
+            float g[5] = {360 * uni(), 180 * uni(), 1 + 99 * uni(), 1 + 99 * uni(), 0.0f};
+            float q[5] = {360 * uni(), 180 * uni(), 1 + 99 * uni(), 1 + 99 * uni(), 0.0f};
+            if (fast_cull<4>(g, q, 0)) continue;
+            for (int c = 0; c < 4; c++) { h1[i * 4 + c] = g[c]; h2[i * 4 + c] = q[c]; }
+            i++;
+        }
     }
     float *d1, *d2, *out; unsigned long long* clk;
     (void)hipMalloc(&d1, n * 16); (void)hipMalloc(&d2, n * 16); (void)hipMalloc(&out, n * 4); (void)hipMalloc(&clk, 16);
