@@ -378,6 +378,15 @@ struct PlanarPair {
 #else
 #define SPH_ANY_LANE(cond) (cond)
 #endif
+// diagnostic: -DSPH_GUARDS_OFF=<bit mask> compiles the guarded block of site k out (tools/ubench/finish_rate.hip prices
+// the sites one by one); 0 in every build of the library
+#if !defined(SPH_GUARDS_OFF)
+#define SPH_GUARDS_OFF 0
+#endif
+#define SPH_SITE(k) (((SPH_GUARDS_OFF) >> (k)) & 1) ? false :
+#if !defined(SPH_SITE_HIT)
+#define SPH_SITE_HIT(k)   // diagnostic: counts how often a wave enters guarded block k (tools/ubench/finish_rate.hip -DCOUNT_SITES)
+#endif
 
 // Stage 1 + planar boxes for one pair of spherically jittered boxes (degrees): the closed-form front end shared by the
 // IoU kernels (lean_finish) and the loss kernels (loss_front_fast) — one source for the planar pair, so that the IoU the
@@ -429,21 +438,28 @@ SPH_DEV void lean_front(const float (&x1)[5], const float (&x2)[5], int edge, Pl
     if (GATES) o.g_A = A > Amin;
     A = fmaxf(A, Amin);
     float ca = D * iS, sa = N * iS, cb = Dp * iS, sb = Np * iS;
-    if (SPH_ANY_LANE(!(S2 > 1e-30f))) {
-        // exactly coincident (or exactly antipodal) centres: the bearing is undefined (0/0).  N and D are products,
-        // not differences, so they stay meaningful down to ~1e-15 (e.g. two boxes clamped onto a pole: A ~ 1e-7 but
-        // the bearings still differ by the longitude difference); only a literal zero needs a convention: a = pi/2.
-        if (!(S2 > 1e-30f)) { ca = 0.0f; sa = 1.0f; cb = 0.0f; sb = 1.0f; }
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("");   // keeps this a skipped block: if-converted it costs every pass four v_mov under an empty mask
-#endif
-    }
+    // exactly coincident (or exactly antipodal) centres: the bearing is undefined (0/0).  N and D are products, not
+    // differences, so they stay meaningful down to ~1e-15 (e.g. two boxes clamped onto a pole: A ~ 1e-7 but the bearings
+    // still differ by the longitude difference); only a literal zero needs a convention: a = pi/2.
+    const bool coincident = !(S2 > 1e-30f);
+    auto fix_coincident = [&]() {
+        if (coincident) { ca = 0.0f; sa = 1.0f; cb = 0.0f; sb = 1.0f; }
+    };
     float ga = 0.0f, gb = 0.0f;
-    // the reference's sign * |acos(clamp(cos a))| floors |a| and |pi - a| at kMinAng (angle_floor)
-    auto floors = [&]() {
+    // the reference's sign * |acos(clamp(cos a))| floors |a| and |pi - a| at kMinAng (angle_floor).  ONE guard for the
+    // coincident-centre fix and the floors where the floors come first (every guard ends a basic block at a branch that
+    // waits for its compare: see SPH_ANY_LANE); a coincident pair's sines are NaN or inf, so its lane needs no floor
+    // compare of its own before the fix, and after it (sin = 1) none applies.
+    auto floors = [&](bool with_coincident) {
         const bool fa = fabsf(sa) < kMinAng, fb = fabsf(sb) < kMinAng;
-        if (GATES) { o.g_ag = !fa; o.g_ap = !fb; }
-        if (SPH_ANY_LANE(fa) || SPH_ANY_LANE(fb)) { angle_floor(ca, sa); angle_floor(cb, sb); }   // (see SPH_ANY_LANE)
+        if (SPH_SITE(1) ((with_coincident && SPH_ANY_LANE(coincident)) || SPH_ANY_LANE(fa) || SPH_ANY_LANE(fb))) {
+            SPH_SITE_HIT(1);
+            bool fa2 = fa, fb2 = fb;
+            if (with_coincident) { fix_coincident(); fa2 = fabsf(sa) < kMinAng; fb2 = fabsf(sb) < kMinAng; }
+            if (GATES) { o.g_ag = !fa2; o.g_ap = !fb2; }
+            angle_floor(ca, sa);
+            angle_floor(cb, sb);
+        } else if (GATES) { o.g_ag = true; o.g_ap = true; }
     };
     if (DIM == 5) {
         ga = x1[4] * kDeg2Rad;
@@ -451,12 +467,13 @@ SPH_DEV void lean_front(const float (&x1)[5], const float (&x2)[5], int edge, Pl
         float sga, cga, sgb, cgb;
         sincos_r(ga, sga, cga);
         sincos_r(gb, sgb, cgb);
-        if (VARIANT == VARIANT_EFFICIENT) floors();   // floor, then a -= gamma
+        if (VARIANT == VARIANT_EFFICIENT) floors(true);   // floor, then a -= gamma
+        else if (SPH_ANY_LANE(coincident)) fix_coincident();
         rot(ca, sa, cga, -sga);
         rot(cb, sb, cgb, -sgb);
-        if (VARIANT == VARIANT_STANDARD) floors();    // d rotated first
+        if (VARIANT == VARIANT_STANDARD) floors(false);    // d rotated first
     } else {
-        floors();
+        floors(true);
     }
     // ---- rotated jitter (sph_iou_api.py:222-242) on (x, w, h, a); its decisions need real angles only when the two
     // angles are within ~1.8e-3 of each other modulo 2 pi ----
@@ -464,9 +481,15 @@ SPH_DEV void lean_front(const float (&x1)[5], const float (&x2)[5], int edge, Pl
     const bool sim_dist = A < e, sim_size = fminf(fabsf(wg - wp), fabsf(hg - hp)) < e;
     bool sim = sim_dist | sim_size;
     bool close = false;
-    bool any_sim_close = SPH_ANY_LANE(sim_dist) || SPH_ANY_LANE(sim_size);   // wave-uniform
-    const bool cand_s = fabsf(s) < 2.0e-3f, cand = (c > 0.5f) & cand_s;
-    if (SPH_ANY_LANE(cand_s)) {   // (the wave-level guard on the sine alone: a single compare's mask, see SPH_ANY_LANE)
+    // candidates for the angle decisions: `close` needs |a1 - a2| < ea = 1.2346e-3 after a possible shift of the difference
+    // by 4e = 4.94e-4 (`sim`), i.e. |a_g - a_p| < 1.729e-3 — and 0.54 % of the benchmark's survivors are within 2e-3 (the
+    // two bearings of a pair are correlated), which sends every third 64-lane pass through this block
+    const bool cand_s = fabsf(s) < 1.75e-3f, cand = (c > 0.5f) & cand_s;
+    float dx = A, dy = 0.0f;
+    // ONE guard for the decisions and the adjustments (the wave-level test of the candidates is on the sine alone: a
+    // single compare's mask, see SPH_ANY_LANE)
+    if (SPH_SITE(2) (SPH_ANY_LANE(cand_s) || SPH_ANY_LANE(sim_dist) || SPH_ANY_LANE(sim_size))) {
+        SPH_SITE_HIT(2);
         if (cand) {
             float a1, a2;
             if (DIM == 5 && VARIANT == VARIANT_EFFICIENT) {  // a = floor(atan2(N, D)) - gamma, not wrapped
@@ -484,10 +507,7 @@ SPH_DEV void lean_front(const float (&x1)[5], const float (&x2)[5], int edge, Pl
             if (sim) { a1 += e; a2 += (float)(5 * kEpsS); }
             close = fabsf(a1 - a2) < ea;
         }
-        any_sim_close = any_sim_close || SPH_ANY_LANE(sim | close);
-    }
-    float dx = A, dy = 0.0f;
-    if (any_sim_close) {   // constant rotations of (cos, sin) instead of new trig
+        // constant rotations of (cos, sin) instead of new trig
         if (sim) {
             dx += e; dy += e;  // (x, y) += (e, e) vs (2e, 2e)
             wg += (float)(2 * kEpsS); hg += (float)(2 * kEpsS); wp += e; hp += e;
@@ -556,7 +576,8 @@ SPH_DEV float lean_finish(const float (&in1)[5], const float (&in2)[5], int mode
     for (int k = 0; k < 5; k++) { x1[k] = in1[k]; x2[k] = in2[k]; }
 #pragma unroll
     for (int k = 0; k < DIM; k++) similar |= fabsf(in1[k] - in2[k]) < e;
-    if (SPH_ANY_LANE(similar)) {
+    if (SPH_SITE(0) SPH_ANY_LANE(similar)) {
+        SPH_SITE_HIT(0);
         const float sh1 = similar ? e2 : 0.0f, sh2 = similar ? e : 0.0f;  // x - 0 == x exactly
 #pragma unroll
         for (int k = 0; k < DIM; k++) { x1[k] = x1[k] - sh1; x2[k] = x2[k] + sh2; }
@@ -583,7 +604,8 @@ SPH_DEV float lean_finish(const float (&in1)[5], const float (&in2)[5], int mode
     // the two jitter steps cancelled: DESIGN.md §9.  (Two compares and a scalar OR of their masks; written as one
     // condition the compiler turns them into abs / canonicalise / min / compare: five VALU instructions)
     const bool near_s = fabsf(q.s) < kNearParallel, near_c = fabsf(q.c) < kNearParallel;
-    if (SPH_ANY_LANE(near_s) || SPH_ANY_LANE(near_c)) {
+    if (SPH_SITE(3) (SPH_ANY_LANE(near_s) || SPH_ANY_LANE(near_c))) {
+        SPH_SITE_HIT(3);
         if (near_s | near_c) t2 = 2.0f * near_parallel_inter(pax, pay, q.c, q.s, hwa, hha, hwb, hhb);
     }
     const float inter = 0.5f * clampf(t2, 0.0f, 3.0e38f);

@@ -1,0 +1,82 @@
+"""-m gpu: the one-round chunk kernel (one wave = 128 consecutive pairs: cull, compact on the wave's LDS stack, finish)
+at the sizes and survivor counts where its bookkeeping can go wrong: batches that end inside a chunk / a slice / a
+workgroup, chunks with no survivor, with exactly 64, with more than 64 (second pass) and with all 128 surviving.  The
+referee is the same arithmetic evaluated one lane per pair through the pairwise entry point (`is_aligned=False` on
+single rows: no compaction, no chunks) — bit for bit — and the CPU oracle within the parity bound.
+Reference: sphdet/iou/sph_iou_api.py:48-86 (aligned mode: row i of bboxes1 against row i of bboxes2)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mixed(n, dim, seed, frac_near):
+    """uniform boxes (60 % culled) with a controlled share of near-duplicates (always survive)"""
+    from oracle import oracle as O
+    rng = np.random.default_rng(seed)
+    b1 = O.generate_boxes(n, seed, box='rbfov' if dim == 5 else 'bfov')
+    b2 = O.generate_boxes(n, seed + 1, box='rbfov' if dim == 5 else 'bfov')
+    near = rng.random(n) < frac_near
+    b2[near] = b1[near] + rng.standard_normal((int(near.sum()), dim)).astype(np.float32) * 2.0
+    b2[:, 0] %= 360.0
+    b2[:, 1:4] = b2[:, 1:4].clip(1, 179)
+    return b1, np.ascontiguousarray(b2)
+
+
+@pytest.mark.parametrize('dim', [4, 5])
+@pytest.mark.parametrize('n', [1, 63, 64, 65, 127, 128, 129, 255, 511, 512, 513, 1023, 4097, 100003])
+def test_ragged_sizes_match_one_lane_per_pair_bit_for_bit(n, dim):
+    import torch
+    import sph_retina_amd as S
+    for frac in (0.0, 0.5, 1.0):   # 40 % / 70 % / 100 % survivors: one pass, sometimes two, always two
+        b1, b2 = _mixed(n, dim, 11 + n % 7, frac)
+        t1, t2 = torch.from_numpy(b1).cuda(), torch.from_numpy(b2).cuda()
+        for fn in (S.sph2pob_standard_iou, S.sph2pob_efficient_iou):
+            got = fn(t1, t2, is_aligned=True)
+            assert got.shape == (n,)
+            # referee: chunks of the same pairs through the pairwise kernel's diagonal (other launch shape, other kernel)
+            m = min(n, 300)
+            ref = torch.stack([fn(t1[i:i + 1], t2[i:i + 1])[0, 0] for i in range(m)])
+            assert torch.equal(got[:m], ref), (n, dim, frac, fn.__name__)
+            # and the tail of the batch (the last, partial chunk)
+            tail = range(max(n - 70, 0), n)
+            ref = torch.stack([fn(t1[i:i + 1], t2[i:i + 1])[0, 0] for i in tail])
+            assert torch.equal(got[max(n - 70, 0):], ref)
+
+
+def test_survivor_counts_around_64_and_output_not_touched_past_n():
+    """chunks whose survivor count is exactly 0 / 1 / 63 / 64 / 65 / 128; the output buffer beyond n stays as it was"""
+    import torch
+    import sph_retina_amd as S
+    from oracle import oracle as O
+    base = O.generate_boxes(128, 5)
+    far = base.copy()
+    far[:, 0] = (far[:, 0] + 180.0) % 360.0
+    far[:, 1] = 180.0 - far[:, 1]          # antipodal boxes: culled for every size below
+    base[:, 2:4] = base[:, 2:4].clip(1, 40)
+    far[:, 2:4] = base[:, 2:4]
+    for survivors in (0, 1, 63, 64, 65, 128):
+        b2 = far.copy()
+        b2[:survivors] = base[:survivors] + 0.5   # overlapping partner
+        b2[:, 1:4] = b2[:, 1:4].clip(1, 179)
+        reps = 5   # five chunks in a row, the same pattern in each
+        t1 = torch.from_numpy(np.tile(base, (reps, 1))).cuda()
+        t2 = torch.from_numpy(np.tile(b2, (reps, 1))).cuda()
+        got = S.sph2pob_standard_iou(t1, t2, is_aligned=True).cpu().numpy().reshape(reps, 128)
+        assert (got == got[0]).all()
+        assert (got[0, survivors:] == 0).all()
+        assert (got[0, :survivors] > 0.2).all()
+        want = O.iou_aligned(base[:max(survivors, 1)], b2[:max(survivors, 1)], 'standard', planar='exact', dtype=np.float64)
+        assert np.abs(got[0, :survivors] - want[:survivors]).max(initial=0.0) < 2e-5
+    # raw C ABI: nothing is written past n
+    from sph_retina_amd import _lib, _torch_glue as G
+    import ctypes
+    n = 1000
+    t1 = torch.from_numpy(O.generate_boxes(1024, 1)).cuda()
+    t2 = torch.from_numpy(O.generate_boxes(1024, 2)).cuda()
+    out = torch.full((1024,), -7.0, device='cuda')
+    rc = _lib.lib().sph2pob_iou_aligned_f32(G.ptr(t1), G.ptr(t2), G.ptr(out), ctypes.c_int64(n), 4, 0, 0, 0, 0,
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert (out[n:] == -7.0).all() and (out[:n] >= 0).all()

@@ -5,6 +5,10 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>
+#if defined(COUNT_SITES)
+__device__ unsigned long long g_site_hits[8];
+#define SPH_SITE_HIT(k) do { if ((threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_site_hits[k], 1ull); } while (0)
+#endif
 #if defined(NO_GUARDS)
 #define SPH_ANY_LANE(cond) false   // the common path alone: what the wave-uniform guards of the rare branches cost
 #endif
@@ -75,5 +79,18 @@ int main() {
             printf("%s waves/SIMD %d: %.3f ms, %.1f ns per wave-pass per SIMD = %.0f cycles at the in-kernel clock %.3f GHz (lone-wave latency view: %.1f ns per pass)\n",
                    what == 0 ? "lean_finish" : "fast_cull  ", wps, ms, ns_per_pass_per_simd, ns_per_pass_per_simd * ghz, ghz, ms * 1e6 / iters);
         }
+#if defined(COUNT_SITES)
+    {
+        unsigned long long z[8] = {0}, h[8];
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_site_hits), z, sizeof(z));
+        const int wgs = 256 * 8, iters = 400;
+        k<0><<<wgs, 256>>>(d1, d2, out, iters, clk);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_site_hits), sizeof(h));
+        const double passes = (double)wgs * 4 * iters;
+        printf("share of the passes that enter a guarded block: spherical shift %.4f  floors %.4f  rotated jitter %.4f  near-parallel %.4f\n",
+               h[0] / passes, h[1] / passes, h[2] / passes, h[3] / passes);
+    }
+#endif
     return 0;
 }
