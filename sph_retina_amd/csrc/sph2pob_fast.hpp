@@ -289,7 +289,9 @@ SPH_DEV bool cull_pair(const CullBox& g, const CullBox& p) {
     float R2 = R * R;
     float cosR_lb = fmaf(fmaf(fmaf(-1.0f / 720.0f, R2, 1.0f / 24.0f), R2, -0.5f), R2, 1.0f);
     float C = g.c * p.c + (g.s * p.s) * hw_cos_rev(p.th_rev - g.th_rev);
-    return (R < 3.0f) & (C < cosR_lb - 1e-4f);
+    // (no separate test of R: the bound decreases in R^2 on the whole axis and is below -1.12 from R^2 = 8.9 on, where
+    // no cosine can be below it — see fast_cull; R = +inf or NaN makes the bound -inf or NaN: never culled)
+    return C < cosR_lb - 1e-4f;
 }
 // Aligned form of the same test with 4 quarter-rate instructions instead of 7 (a quarter-rate op costs 8 plain FMAs):
 //   cos(angular distance) = 1/2 [cos(phi_g - phi_p) (1 + cos dtheta) + cos(phi_g + phi_p) (1 - cos dtheta)]   (3 v_cos)

@@ -357,14 +357,20 @@ __global__ __launch_bounds__(kBlock, DIM == 4 ? 8 : 7) void iou_aligned_chunk_ke
 // ~15 VALU instructions + one coalesced store of 0.  Survivors are (row, column) index pairs pushed on the wave's
 // LDS stack and finished 64 at a time on fully populated waves (same scheme as iou_aligned_compact_kernel).
 constexpr int kPwRows = 64;
-template <int VARIANT, int DIM>
-__global__ __launch_bounds__(kBlock) void iou_pairwise_compact_kernel(const float* __restrict__ b1, int m,
+// ARC: rbb_edge == 'arc' folded at compile time, as in the aligned kernels (with a run-time edge the chord / tangent forms
+// made this kernel 47 KB of code at 84 VGPRs).  The < 64 leftovers of the four waves are merged once at the end and
+// finished on as few, as full waves as possible (with 8 rows per workgroup a wave stacks ~80 survivors: one full pass and
+// a 16-lane one without the merge).
+template <int VARIANT, int DIM, bool ARC>
+__global__ __launch_bounds__(kBlock, ARC ? 8 : 4) void iou_pairwise_compact_kernel(const float* __restrict__ b1, int m,
                                                                      const float* __restrict__ b2, int n,
-                                                                     float* __restrict__ out, int mode, int edge,
+                                                                     float* __restrict__ out, int mode, int edge_arg,
                                                                      int rows_per_wg) {
     __shared__ float row_raw[kPwRows][5];
     __shared__ float4 row_cull[kPwRows];
     __shared__ int2 stack[kBlock / 64][kQCap];
+    __shared__ int leftover[kBlock / 64];
+    const int edge = ARC ? (int)EDGE_ARC : edge_arg;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = blockIdx.y * rows_per_wg, rows = (m - r0 < rows_per_wg) ? m - r0 : rows_per_wg;
     if ((int)threadIdx.x < rows) {
@@ -390,13 +396,12 @@ __global__ __launch_bounds__(kBlock) void iou_pairwise_compact_kernel(const floa
         load_box<DIM>(b2, e.y, p);
         out[(int64_t)(r0 + e.x) * n + e.y] = lean_finish<VARIANT, DIM>(g, p, mode, edge);
     };
+    float* orow = out + (int64_t)r0 * n + j;   // this column's element of the tile's first row
     for (int i = 0; i < rows; i++) {
         const float4 rc = row_cull[i];
-        bool surv = false;
-        if (valid) {
-            if (cull_pair(CullBox{rc.x, rc.y, rc.z, rc.w}, ca)) out[(int64_t)(r0 + i) * n + j] = 0.0f;
-            else surv = true;
-        }
+        const bool culled = cull_pair(CullBox{rc.x, rc.y, rc.z, rc.w}, ca), surv = valid & !culled;
+        if (valid & culled) *orow = 0.0f;
+        orow += n;
         const unsigned long long mk = __builtin_amdgcn_ballot_w64(surv);
         if (surv) st[count + rank_below(mk)] = make_int2(i, j);
         count += __popcll(mk);
@@ -406,8 +411,20 @@ __global__ __launch_bounds__(kBlock) void iou_pairwise_compact_kernel(const floa
             finish_one(st[count + lane]);
         }
     }
-    wave_lds_fence();
-    if (lane < count) finish_one(st[lane]);
+    // merge the < 64 leftovers of the four waves
+    if (lane == 0) leftover[wave] = count;
+    // LDS only: __syncthreads() would also wait for the acknowledgement of every store above (vmcnt(0))
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int c0 = leftover[0], c1 = leftover[1], c2 = leftover[2], c3 = leftover[3];
+    const int total = c0 + c1 + c2 + c3;   // <= 252: at most one chunk per wave
+    if (wave * 64 < total) {
+        int k = wave * 64 + lane;
+        if (k < total) {
+            int w = 0;
+            if (k >= c0) { k -= c0; w = 1; if (k >= c1) { k -= c1; w = 2; if (k >= c2) { k -= c2; w = 3; } } }
+            finish_one(stack[w][k]);
+        }
+    }
 }
 
 // out[i*n + j]: consecutive lanes walk j (coalesced stores, b2 loads coalesced, b1 row is a broadcast).
@@ -1091,8 +1108,12 @@ struct PairwiseLaunch {
             if (rpw > kPwRows) rpw = kPwRows;
             if (rpw > m) rpw = m;
             dim3 grid((unsigned)col_tiles, (unsigned)((m + rpw - 1) / rpw));
-            hipLaunchKernelGGL((iou_pairwise_compact_kernel<V >= 2 ? 0 : V, D>), grid, dim3(kBlock), 0, s, b1, (int)m, b2, (int)n,
-                               out, mode, edge, (int)rpw);
+            if (edge == SPH2POB_EDGE_ARC)
+                hipLaunchKernelGGL((iou_pairwise_compact_kernel<V >= 2 ? 0 : V, D, true>), grid, dim3(kBlock), 0, s, b1, (int)m, b2, (int)n,
+                                   out, mode, edge, (int)rpw);
+            else
+                hipLaunchKernelGGL((iou_pairwise_compact_kernel<V >= 2 ? 0 : V, D, false>), grid, dim3(kBlock), 0, s, b1, (int)m, b2, (int)n,
+                                   out, mode, edge, (int)rpw);
             return launch_status();
         }
         // grid.y is limited to 65535 rows per launch: walk the rows in slabs
