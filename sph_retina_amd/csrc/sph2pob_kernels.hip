@@ -487,6 +487,13 @@ __device__ __forceinline__ float element_weight(const float* __restrict__ w, int
     return s / (float)wd;
 }
 
+// waves per SIMD the loss kernels that carry the adjoint are compiled for (closed-form front end): 4 = ~105 VGPRs, no
+// scratch; 5 = 96 VGPRs with 2-5 spilled dwords; 6 = 80 VGPRs with ~20.  Measured on MI355X, 1 M RBFoV pairs, CIoU
+// forward + backward through the C ABI: 30.5-30.8 us / 31.2-31.9 us / 41.6 us (profiles/r02t_loss_waves.log): 4 stays.
+#if !defined(SPH_LOSS_WAVES)
+#define SPH_LOSS_WAVES 4
+#endif
+constexpr int kLossWaves = SPH_LOSS_WAVES;
 template <int DIM, bool FAST>
 __global__ __launch_bounds__(kBlock) void loss_fwd_kernel(const float* __restrict__ pred,
                                                          const float* __restrict__ target,
@@ -536,7 +543,7 @@ __global__ __launch_bounds__(kBlock) void loss_fwd_sum_kernel(const float* __res
 }
 
 template <int DIM, bool FAST>
-__global__ __launch_bounds__(kBlock) void loss_bwd_kernel(const float* __restrict__ pred,
+__global__ __launch_bounds__(kBlock, FAST ? kLossWaves : 4) void loss_bwd_kernel(const float* __restrict__ pred,
                                                          const float* __restrict__ target,
                                                          const float* __restrict__ weight, int wd,
                                                          const float* __restrict__ grad_out, int grad_stride,
@@ -570,7 +577,7 @@ __global__ __launch_bounds__(kBlock) void loss_bwd_kernel(const float* __restric
 
 // forward + gradients for an upstream gradient of 1 (+ per-workgroup partial sum of the loss when `partial`)
 template <int DIM, bool FAST>
-__global__ __launch_bounds__(kBlock) void loss_fwd_grad_kernel(const float* __restrict__ pred,
+__global__ __launch_bounds__(kBlock, FAST ? kLossWaves : 4) void loss_fwd_grad_kernel(const float* __restrict__ pred,
                                                               const float* __restrict__ target,
                                                               const float* __restrict__ weight, int wd, float scale,
                                                               float* __restrict__ loss, float* __restrict__ partial,
