@@ -80,3 +80,32 @@ def test_survivor_counts_around_64_and_output_not_touched_past_n():
     assert rc == 0
     torch.cuda.synchronize()
     assert (out[n:] == -7.0).all() and (out[:n] >= 0).all()
+
+
+@pytest.mark.parametrize('edge', ['arc', 'chord'])
+@pytest.mark.parametrize('dim', [4, 5])
+def test_pairwise_tiles_with_merged_leftovers_match_aligned_bit_for_bit(dim, edge):
+    """the assigner kernel (rows x columns tiles, survivors stacked per wave, the four waves' leftovers merged behind an
+    LDS-only barrier) at row / column counts that end inside a tile, with few and with many survivors per wave"""
+    import torch
+    import sph_retina_amd as S
+    from oracle import oracle as O
+    box = 'rbfov' if dim == 5 else 'bfov'
+    for m, n in ((1, 1), (1, 257), (7, 255), (8, 256), (9, 1000), (64, 513), (65, 300), (130, 77)):
+        b1 = O.generate_boxes(m, 21 + m, box=box)
+        b2 = O.generate_boxes(n, 22 + n, box=box)
+        k = min(m, n)
+        b2[:k] = b1[:k] + 1.0            # a diagonal of certain survivors on top of the ~40 % that pass the cull
+        b2[:, 1:4] = b2[:, 1:4].clip(1, 179)
+        t1, t2 = torch.from_numpy(b1).cuda(), torch.from_numpy(np.ascontiguousarray(b2)).cuda()
+        for fn in (S.sph2pob_standard_iou, S.sph2pob_efficient_iou):
+            pw = fn(t1, t2, rbb_edge=edge)
+            al = fn(t1.repeat_interleave(n, 0), t2.repeat(m, 1), is_aligned=True, rbb_edge=edge)
+            assert pw.shape == (m, n)
+            assert torch.equal(pw.reshape(-1), al), (m, n, dim, edge, fn.__name__)
+        # every pair survives: columns = copies of the rows' boxes, slightly moved
+        if m <= 9:
+            t2 = (t1[torch.arange(n) % m] + 0.25).contiguous()
+            pw = S.sph2pob_standard_iou(t1, t2, rbb_edge=edge)
+            al = S.sph2pob_standard_iou(t1.repeat_interleave(n, 0), t2.repeat(m, 1), is_aligned=True, rbb_edge=edge)
+            assert torch.equal(pw.reshape(-1), al)
