@@ -829,25 +829,33 @@ __global__ __launch_bounds__(kBlock) void nms_sweep_kernel(const unsigned long l
         for (int w = threadIdx.x; w <= b_last; w += kBlock) removed[w] = 0ull;
         for (int64_t r = (base + b_last + 1) * 64 + threadIdx.x; r < seg_end; r += kBlock) keep[r] = 0;
         __syncthreads();
+        // the diagonal word of a block's rows depends on nothing the sweep computes: the next block's is requested
+        // while this block is resolved (the load's latency was on every block's critical path)
+        auto load_diag = [&](int b) -> unsigned long long {
+            const int64_t row = (base + b) * 64 + lane;
+            return (wave == 0 && b <= b_last && row >= s && row < seg_end) ? mask[row * words + b] : 0ull;
+        };
+        unsigned long long diag_next = load_diag(0);
         for (int b = 0; b <= b_last; b++) {
             const int64_t row0 = (base + b) * 64;
             if (wave == 0) {
                 const int64_t row = row0 + lane;
                 const bool mine = row >= s && row < seg_end;
-                const unsigned long long diag = mine ? mask[row * words + b] : 0ull;
+                const unsigned long long diag = diag_next;
+                diag_next = load_diag(b + 1);
                 const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
                 // scalar (SGPR) state of the serial chain; rows of the block outside this segment start out "removed"
                 // (the readlane builtins return int: cast before widening, or bit 31 sign-extends)
                 unsigned long long rem = removed[b] | ~__builtin_amdgcn_ballot_w64(mine);
                 rem = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(rem >> 32)) << 32) |
                       (unsigned)__builtin_amdgcn_readfirstlane((unsigned)rem);
+                // one step per KEPT row (s_ff1 on the rows still alive), not per row: a dense scene keeps a few of 64
                 unsigned long long keepbits = 0ull;
-                for (int r = 0; r < 64; r++) {
-                    if (!((rem >> r) & 1ull)) {
-                        keepbits |= 1ull << r;
-                        rem |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, r) << 32) |
-                               (unsigned)__builtin_amdgcn_readlane(dlo, r);
-                    }
+                while (~rem != 0ull) {
+                    const int r = __builtin_ctzll(~rem);
+                    keepbits |= 1ull << r;
+                    rem |= (1ull << r) | ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, r) << 32) |
+                           (unsigned)__builtin_amdgcn_readlane(dlo, r);
                 }
                 if (mine) keep[row] = (unsigned char)((keepbits >> lane) & 1ull);
                 if (lane == 0) kept_sh = keepbits;
