@@ -17,8 +17,12 @@ SOURCES = ['sph2pob_kernels.hip', 'sph2pob_coder.hip']
 HEADERS = ['sph2pob_device.hpp', 'sph2pob_loss.hpp', 'sph2pob_fast.hpp', 'sph2pob_unbiased.hpp', os.path.join('..', '..', 'include', 'sph2pob_hip.h')]
 # -fno-slp-vectorize: hipcc otherwise pairs scalar fp32 mul/add into v_pk_* (+ v_mov shuffles); packed fp32 issues at
 # half the rate of plain VALU on gfx950 (tools/ubench/valu_rate2.hip), measured 12 % slower on the dominant kernel
+# -amdgpu-kernarg-preload-count: gfx950 hands the first kernel arguments to a wave in SGPRs at launch instead of making
+# every wave fetch them with s_load (two dependent scalar loads stood in front of the first global load of the dominant
+# kernel): 8.24 -> 8.04 us per 1 M pairs, 4.29 -> 4.11 at 250 k (profiles/r02w_ab_*.log); the compiler keeps a
+# compatible entry for firmware without the feature
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
-               '-fno-slp-vectorize'] + \
+               '-fno-slp-vectorize', '-mllvm', '-amdgpu-kernarg-preload-count=16'] + \
     os.environ.get('SPH2POB_EXTRA_HIPCC_FLAGS', '').split()
 
 _c_f32p = ctypes.c_void_p
