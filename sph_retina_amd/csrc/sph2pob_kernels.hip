@@ -274,6 +274,8 @@ __global__ __launch_bounds__(kBlock, REF ? 4 : (DIM == 4 ? 7 : 5)) void iou_alig
 //     barrier, chunks assigned or claimed from a counter) so that all passes but one per workgroup are full: 12 % fewer
 //     finishing instructions at 8 waves and NO gain (8.8-8.95 us at 1 M, 55-57 at 8 M; r02l_ab_pool_*.log) — the
 //     barrier couples waves that sit on different SIMDs; built, measured, removed;
+//   * workgroups of 1 / 2 / 4 / 8 / 16 independent waves: the same within 1 % from 100 k to 8 M pairs (16: +3 %;
+//     r02z_ab_wg*.log); 4 stays;
 //   * rotating which wave of the persistent form takes which leftover chunk: the hardware already rotates the
 //     wave -> SIMD placement from workgroup to workgroup (tools/ubench/hwid.hip); +0.3 us, removed.
 template <int DIM, int SLICES>
@@ -282,16 +284,16 @@ struct ChunkQueue {
     int idx[64 * SLICES];
 };
 constexpr int kChunkSlices = 2;
-template <int VARIANT, int DIM, bool ARC, int SLICES>
-__global__ __launch_bounds__(kBlock, DIM == 4 ? 8 : 7) void iou_aligned_chunk_kernel(const float* __restrict__ b1, const float* __restrict__ b2,
+template <int VARIANT, int DIM, bool ARC, int SLICES, int WAVES = kBlock / 64>
+__global__ __launch_bounds__(64 * WAVES, DIM == 4 ? 8 : 7) void iou_aligned_chunk_kernel(const float* __restrict__ b1, const float* __restrict__ b2,
                                                                       float* __restrict__ out, int n, int mode, int edge_arg) {
-    __shared__ ChunkQueue<DIM, SLICES> queues[kBlock / 64];
+    __shared__ ChunkQueue<DIM, SLICES> queues[WAVES];
     const int edge = ARC ? (int)EDGE_ARC : (edge_arg & 0xff);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     ChunkQueue<DIM, SLICES>& q = queues[wave];
-    const int base = (blockIdx.x * (kBlock / 64) + wave) * (64 * SLICES);
+    const int base = (blockIdx.x * WAVES + wave) * (64 * SLICES);
     if (base >= n) return;   // wave-uniform; the kernel has no barrier
-    const int wave_global = blockIdx.x * (kBlock / 64) + wave;
+    const int wave_global = blockIdx.x * WAVES + wave;
     (void)wave_global;
     SPH_STAMP(0);
     SPH_STAMP_WHERE();
