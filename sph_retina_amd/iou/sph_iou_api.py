@@ -46,17 +46,17 @@ def _sph2pob_iou_auxiliary(bboxes1, bboxes2, variant, mode, is_aligned, calculat
         # calculator='diff'): IoU = 1 - (IoU-mode loss element), gradients from the fused loss backward kernel
         from ..losses.sph2pob_iou_loss import sph2pob_iou_loss
         return 1.0 - sph2pob_iou_loss(bboxes1, bboxes2, mode='iou', reduction='none')
-    b1, b2 = G.as_f32(bboxes1.detach()), G.as_f32(bboxes2.detach())
+    b1, b2 = G.as_f32_nograd(bboxes1), G.as_f32_nograd(bboxes2)
     if is_aligned:
         assert rows == cols
         out = torch.empty((rows,), dtype=torch.float32, device=b1.device)
-        G.call('sph2pob_iou_aligned_f32', b1.device, G.ptr(b1), G.ptr(b2), G.ptr(out), ctypes.c_int64(rows), dim,
-               G.VARIANTS[variant], mode_c, edge_c, angle_c, G.stream_of(b1))
+        G.call('sph2pob_iou_aligned_f32', b1.device, G.ptr(b1), G.ptr(b2), G.ptr(out), rows, dim,
+               G.VARIANTS[variant], mode_c, edge_c, angle_c, G.raw_stream_of(b1.device))
     else:
         out = torch.empty((rows, cols), dtype=torch.float32, device=b1.device)
-        G.call('sph2pob_iou_pairwise_f32', b1.device, G.ptr(b1), ctypes.c_int64(rows), G.ptr(b2),
-               ctypes.c_int64(cols), G.ptr(out), dim, G.VARIANTS[variant], mode_c, edge_c, angle_c,
-               G.stream_of(b1))
+        G.call('sph2pob_iou_pairwise_f32', b1.device, G.ptr(b1), rows, G.ptr(b2),
+               cols, G.ptr(out), dim, G.VARIANTS[variant], mode_c, edge_c, angle_c,
+               G.raw_stream_of(b1.device))
     # fp64 / fp16 / bf16 boxes get their dtype back (computed in fp32); integer boxes get fp32 IoUs
     return out if bboxes1.dtype == torch.float32 or not bboxes1.is_floating_point() else out.to(bboxes1.dtype)
 
