@@ -44,6 +44,7 @@ static bool g_persistent = getenv("SPH2POB_ALIGNED_KERNEL") != nullptr && getenv
 template <int DIM>
 __device__ __forceinline__ void load_box(const float* __restrict__ p, int64_t i, float (&b)[5]) {
     if (DIM == 4) {  // one 16-byte load per lane: 1 KiB per wave instruction, fully coalesced
+        // (non-temporal loads: 8.32 vs 8.04 us at 1 M pairs, 51.1 vs 50.4 at 8 M, 97.8 vs 104.1 at 16 M: not kept)
         float4 v = reinterpret_cast<const float4*>(p)[i];
         b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w; b[4] = 0.0f;
     } else {
