@@ -493,21 +493,28 @@ SPH_DEV void lean_front(const float (&x1)[5], const float (&x2)[5], int edge, Pl
     if (SPH_SITE(2) (SPH_ANY_LANE(cand_s) || SPH_ANY_LANE(sim_dist) || SPH_ANY_LANE(sim_size))) {
         SPH_SITE_HIT(2);
         if (cand) {
-            float a1, a2;
+            float dang;   // a_g - a_p as the reference forms it: the difference of two angles in [-pi, pi], not wrapped
             if (DIM == 5 && VARIANT == VARIANT_EFFICIENT) {  // a = floor(atan2(N, D)) - gamma, not wrapped
                 float c1 = D * iS, s1 = N * iS, c2 = Dp * iS, s2 = Np * iS;
                 if (!(S2 > 1e-30f)) { c1 = 0.0f; s1 = 1.0f; c2 = 0.0f; s2 = 1.0f; }
                 angle_floor(c1, s1);
                 angle_floor(c2, s2);
-                a1 = atan2_r(s1, c1) - ga;
-                a2 = atan2_r(s2, c2) - gb;
+                dang = (atan2_r(s1, c1) - ga) - (atan2_r(s2, c2) - gb);
             } else {
-                a1 = atan2_r(sa, ca);
-                a2 = atan2_r(sb, cb);
+#if defined(SPH_ATAN_DECISIONS)
+                dang = atan2_r(sa, ca) - atan2_r(sb, cb);
+#else
+                // from the sine of the difference (|s| < 1.75e-3, c > 0.5: asin s = s + s^3 / 6 to 1e-17), which resolves
+                // the thresholds to ~1e-10 where the difference of two rounded angles near pi carries ~5e-7; the two
+                // angles are on opposite sides of the +-pi cut — their difference is ~2 pi, no decision fires — exactly
+                // when both cosines are negative and the sines differ in sign (the floors keep |sin| >= 4.88e-4)
+                const bool straddle = (ca < 0.0f) & ((sa < 0.0f) != (sb < 0.0f));
+                dang = straddle ? 6.0f : fmaf(s * s, s * (1.0f / 6.0f), s);
+#endif
             }
-            sim |= fabsf(a1 - a2) < e;
-            if (sim) { a1 += e; a2 += (float)(5 * kEpsS); }
-            close = fabsf(a1 - a2) < ea;
+            sim |= fabsf(dang) < e;
+            if (sim) dang -= (float)(4 * kEpsS);   // a_g += e, a_p += 5 e
+            close = fabsf(dang) < ea;
         }
         // constant rotations of (cos, sin) instead of new trig
         if (sim) {
