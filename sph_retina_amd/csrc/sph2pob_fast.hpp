@@ -229,7 +229,16 @@ SPH_DEV float lin_excess(float fl, float fr, float lim, float W) {
     const float part = span > 0.0f ? 0.5f * e * e * W / span : 0.0f;
     return lim <= fmin ? (0.5f * (fmin + fmax) - lim) * W : part;
 }
-SPH_DEV float near_parallel_inter(float px, float py, float c, float s, float hw, float hh, float X, float Y) {
+// A CALLED function (values in, one value out; `lin_excess` inlined into it): inlined, its ~250 instructions and their registers weighed
+// on the common path of every finishing pass although one pass in thirty enters it — 7.94 -> 7.75 us per 1 M pairs,
+// 50.9 -> 49.7 us per 8 M, the same bits (profiles/r03a_ab_nearcall_*.log)
+#if defined(SPH_NEAR_INLINE)
+SPH_DEV
+#else
+__host__ __device__ __attribute__((noinline)) inline
+#endif
+float near_parallel_inter(float px, float py, float c, float s, float hw, float hh, float X,
+                                                                               float Y) {
     float a = hw, b = hh;
     if (fabsf(c) < fabsf(s)) {   // nearly perpendicular: same rectangle, axes rotated by a quarter turn, extents swapped
         const float c2 = s > 0.0f ? s : -s, s2 = s > 0.0f ? -c : c;
