@@ -28,7 +28,9 @@ over ranks.
 Extra objects on the JSON line:
   roofline      the dominant kernel (iou_aligned_chunk_kernel) against the HBM roofline: algorithmic bytes = 36 B/pair
                 (2 x 16 B boxes in + 4 B IoU out) / average launch duration measured here with HIP events
-                on the launch stream.  `traffic` (PMC-measured HBM bytes per launch) and `valu_active_frac` come from
+                on the launch stream (`rocprof_traced_kernel_ms`: the committed rocprofv3 kernel-trace average of the same
+                command, which is 1-1.5 us higher: the tracer brackets every dispatch).  `traffic` (PMC-measured HBM bytes
+                per launch) and `valu_active_frac` come from
                 this round's committed rocprofv3 summary (separate --pmc passes) and are only attached when this run's
                 configuration matches the one profiled; `cold` repeats the measurement rotating through 10 distinct
                 input / output sets (360 MB > the 256 MiB Infinity Cache: every launch streams from HBM), `at_8m` is one
@@ -394,6 +396,10 @@ def main(argv=None):
                                'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc.get('hbm_bytes_per_launch'),
                                'traffic_source': pmc.get('source') if pmc.get('hbm_bytes_per_launch') else None,
                                'valu_active_frac': pmc.get('valu_active_frac'),
+                               # the committed rocprofv3 --kernel-trace --stats average of this command: the tracer brackets
+                               # every dispatch (the launches no longer run back to back from warm caches), which costs this
+                               # kernel 1-1.5 us per launch; bench.py itself reports as much when it is run under the tracer
+                               'rocprof_traced_kernel_ms': (pmc.get('avg_ns') or 0) / 1e6 or None,
                                'kernel': kern, 'kernel_ms': kernel_ms, 'pairs_per_launch': n,
                                'algorithmic_bytes_per_launch': BYTES_PER_PAIR * n}
             if cold:
