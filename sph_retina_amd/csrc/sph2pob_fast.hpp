@@ -369,6 +369,40 @@ struct PlanarPair {
     bool g_A, g_ag, g_ap, g_wg, g_hg, g_wp, g_hp;
 };
 
+// RBFoV `efficient`: the difference of the two planar angles a = floor(atan2(N, D)) - gamma as the reference forms it (not
+// wrapped), for the rotated jitter's decisions on pairs whose directions are within 1.75e-3 of each other.  A called
+// function (two atan2 that a few passes in a hundred need).
+__host__ __device__ __attribute__((noinline)) inline float unwrapped_angle_diff(float D, float N, float Dp, float Np, float iS, float S2,
+                                                                             float ga, float gb) {
+    float c1 = D * iS, s1 = N * iS, c2 = Dp * iS, s2 = Np * iS;
+    if (!(S2 > 1e-30f)) { c1 = 0.0f; s1 = 1.0f; c2 = 0.0f; s2 = 1.0f; }
+    angle_floor(c1, s1);
+    angle_floor(c2, s2);
+    return (atan2_r(s1, c1) - ga) - (atan2_r(s2, c2) - gb);
+}
+
+// |gamma| beyond 177 deg (outside any coder's range): the rotated jitter's angle clamp to [-2pi + 2ea, 2pi - ea] /
+// [-2pi + ea, 2pi - 2ea] (sph_iou_api.py:239-240) may act on a = atan2(.) - gamma.  Returns the clamped directions and
+// whether either angle moved (then the gradient gate of that angle closes).
+struct WideGamma { float ca, sa, cb, sb; bool changed, keep_g, keep_p; };
+template <int VARIANT>
+__host__ __device__ __attribute__((noinline)) inline WideGamma wide_gamma_clamp(float ca, float sa, float cb, float sb, float ga, float gb) {
+    const float ea = (float)kEpsA;
+    const float twopi = 6.283185307179586f;
+    float a1 = atan2_r(sa, ca), a2 = atan2_r(sb, cb);  // wrapped representatives
+    if (VARIANT == VARIANT_EFFICIENT) {                // un-wrap to the reference's real value (|a| < 3*pi)
+        a1 += twopi * rintf((-ga - a1) / twopi);
+        a2 += twopi * rintf((-gb - a2) / twopi);
+    }
+    const float k1 = fminf(fmaxf(a1, -twopi + 2.0f * ea), twopi - ea), k2 = fminf(fmaxf(a2, -twopi + ea), twopi - 2.0f * ea);
+    WideGamma r{ca, sa, cb, sb, k1 != a1 || k2 != a2, k1 == a1, k2 == a2};
+    if (r.changed) {
+        sincos_r(k1 - twopi * rintf(k1 / twopi), r.sa, r.ca);
+        sincos_r(k2 - twopi * rintf(k2 / twopi), r.sb, r.cb);
+    }
+    return r;
+}
+
 // "any lane of the wave": the rare branches of the finishing stage are guarded wave-uniformly, so a wave none of whose
 // lanes needs a branch skips its code with one scalar branch instead of executing it under an empty mask or paying
 // for always-on selects.  On the host (unit tests) a "wave" is one pair.
@@ -504,11 +538,7 @@ SPH_DEV void lean_front(const float (&x1)[5], const float (&x2)[5], int edge, Pl
         if (cand) {
             float dang;   // a_g - a_p as the reference forms it: the difference of two angles in [-pi, pi], not wrapped
             if (DIM == 5 && VARIANT == VARIANT_EFFICIENT) {  // a = floor(atan2(N, D)) - gamma, not wrapped
-                float c1 = D * iS, s1 = N * iS, c2 = Dp * iS, s2 = Np * iS;
-                if (!(S2 > 1e-30f)) { c1 = 0.0f; s1 = 1.0f; c2 = 0.0f; s2 = 1.0f; }
-                angle_floor(c1, s1);
-                angle_floor(c2, s2);
-                dang = (atan2_r(s1, c1) - ga) - (atan2_r(s2, c2) - gb);
+                dang = unwrapped_angle_diff(D, N, Dp, Np, iS, S2, ga, gb);
             } else {
 #if defined(SPH_ATAN_DECISIONS)
                 dang = atan2_r(sa, ca) - atan2_r(sb, cb);
@@ -551,22 +581,13 @@ SPH_DEV void lean_front(const float (&x1)[5], const float (&x2)[5], int edge, Pl
     if (DIM == 5) {
         const bool wide = (fabsf(ga) > 3.1f) | (fabsf(gb) > 3.1f);
         if (SPH_ANY_LANE(wide)) {
-            if (wide) {
-                // |gamma| beyond 177 deg (outside any coder's range): the rotated jitter's angle clamp to
-                // [-2pi + 2ea, 2pi - ea] / [-2pi + ea, 2pi - 2ea] (sph_iou_api.py:239-240) may act on a = atan2(.) - gamma
-                const float twopi = 6.283185307179586f;
-                float a1 = atan2_r(sa, ca), a2 = atan2_r(sb, cb);  // wrapped representatives
-                if (VARIANT == VARIANT_EFFICIENT) {                // un-wrap to the reference's real value (|a| < 3*pi)
-                    a1 += twopi * rintf((-ga - a1) / twopi);
-                    a2 += twopi * rintf((-gb - a2) / twopi);
-                }
-                const float k1 = fminf(fmaxf(a1, -twopi + 2.0f * ea), twopi - ea), k2 = fminf(fmaxf(a2, -twopi + ea), twopi - 2.0f * ea);
-                if (k1 != a1 || k2 != a2) {
-                    sincos_r(k1 - twopi * rintf(k1 / twopi), sa, ca);
-                    sincos_r(k2 - twopi * rintf(k2 / twopi), sb, cb);
+            if (wide) {   // a called function, like near_parallel_inter: ~200 instructions no coder's boxes ever reach
+                const WideGamma r = wide_gamma_clamp<VARIANT>(ca, sa, cb, sb, ga, gb);
+                if (r.changed) {
+                    ca = r.ca; sa = r.sa; cb = r.cb; sb = r.sb;
                     c = fmaf(ca, cb, sa * sb);
                     s = fmaf(sa, cb, -(ca * sb));
-                    if (GATES) { o.g_ag &= k1 == a1; o.g_ap &= k2 == a2; }
+                    if (GATES) { o.g_ag &= r.keep_g; o.g_ap &= r.keep_p; }
                 }
             }
         }
