@@ -447,8 +447,20 @@ __host__ __device__ __attribute__((noinline)) inline WideGamma wide_gamma_clamp(
 // Arithmetic: explicit FMAs, contraction off (see rot) — the same bits from every inlined copy.
 // CLAMPED: the boxes went through jitter_spherical (phi in [0, 180], theta in [0, 360] degrees), which lets the three
 // sincos calls use the cheap quadrant logic (bit-identical on that range).  GATES: also fill in the gradient gates.
-template <int VARIANT, int DIM, bool GATES, bool CLAMPED = true>
-SPH_DEV void lean_front(const float (&x1)[5], const float (&x2)[5], int edge, PlanarPair& o, FastTrig* trig = nullptr) {
+// sin / cos of a box's jittered colatitude, computed once per box where a kernel pairs one box with many (the assigner's
+// tiles): role 1 = a row of bboxes1, role 2 = a row of bboxes2 (the spherical jitter clamps the two roles differently)
+struct ColatTrig { float s, c; };
+SPH_DEV ColatTrig colat_trig(float phi_deg, int role) {
+    const float lo = role == 1 ? (float)(2 * kEpsS) : (float)kEpsS, hi = role == 1 ? (float)(180.0 - kEpsS) : (float)(180.0 - 2 * kEpsS);
+    ColatTrig t;
+    sincos_colat(clampf(phi_deg, lo, hi) * kDeg2Rad, t.s, t.c);
+    return t;
+}
+
+// PRE: the colatitude trig of the two boxes is handed in (`pre1`, `pre2`: exactly what the function would compute)
+template <int VARIANT, int DIM, bool GATES, bool CLAMPED = true, bool PRE = false>
+SPH_DEV void lean_front(const float (&x1)[5], const float (&x2)[5], int edge, PlanarPair& o, FastTrig* trig = nullptr,
+                        ColatTrig pre1 = ColatTrig{0.0f, 1.0f}, ColatTrig pre2 = ColatTrig{0.0f, 1.0f}) {
     const float e = (float)kEpsS, ea = (float)kEpsA;
     // ---- stage 1: accurate trig on the jittered boxes, bearing numerators; degrees -> radians with the reference's
     // rounding (torch.deg2rad: x * fl32(pi/180)) ----
@@ -457,8 +469,8 @@ SPH_DEV void lean_front(const float (&x1)[5], const float (&x2)[5], int edge, Pl
     float wp = edge_length(x2[2] * kDeg2Rad, edge), hp = edge_length(x2[3] * kDeg2Rad, edge);
     float sg, cg, sp, cp, sD, h2;   // sD = sin(theta_p - theta_g), h2 = 1 - cos(theta_p - theta_g)
     if (CLAMPED) {
-        sincos_colat(phg, sg, cg);
-        sincos_colat(php, sp, cp);
+        if (PRE) { sg = pre1.s; cg = pre1.c; sp = pre2.s; cp = pre2.c; }
+        else { sincos_colat(phg, sg, cg); sincos_colat(php, sp, cp); }
         sin_vers_double(0.5f * (thp - thg), sD, h2);
     } else {
         float sh, ch;
@@ -599,8 +611,9 @@ SPH_DEV void lean_front(const float (&x1)[5], const float (&x2)[5], int edge, Pl
 // Spherical jitter + stages 1 + 2 for one pair that survived the cull: clamp(IoU, 0, 1).  The spherical jitter's shift
 // and the near-parallel safeguard are guarded like lean_front's rare branches.  A NaN coordinate gives NaN, as the
 // reference's torch.clamp chain does (sph_iou_api.py:86, :244-260).
-template <int VARIANT, int DIM>
-SPH_DEV float lean_finish(const float (&in1)[5], const float (&in2)[5], int mode, int edge) {
+template <int VARIANT, int DIM, bool PRE = false>
+SPH_DEV float lean_finish(const float (&in1)[5], const float (&in2)[5], int mode, int edge, ColatTrig pre1 = ColatTrig{0.0f, 1.0f},
+                          ColatTrig pre2 = ColatTrig{0.0f, 1.0f}) {
     const float e = (float)kEpsS, e2 = (float)(2 * kEpsS);
     // evaluated HERE, not where it is used: left to the scheduler the test sinks to the end of the pass and keeps the
     // eight raw coordinates alive (and copied) through all of it
@@ -620,6 +633,7 @@ SPH_DEV float lean_finish(const float (&in1)[5], const float (&in2)[5], int mode
         const float sh1 = similar ? e2 : 0.0f, sh2 = similar ? e : 0.0f;  // x - 0 == x exactly
 #pragma unroll
         for (int k = 0; k < DIM; k++) { x1[k] = x1[k] - sh1; x2[k] = x2[k] + sh2; }
+        if (PRE && similar) { pre1 = colat_trig(x1[1], 1); pre2 = colat_trig(x2[1], 2); }   // the shifted colatitudes
     }
     x1[0] = clampf(x1[0], e2, (float)(360.0 - kEpsS));
     x2[0] = clampf(x2[0], e, (float)(360.0 - 2 * kEpsS));
@@ -630,7 +644,7 @@ SPH_DEV float lean_finish(const float (&in1)[5], const float (&in2)[5], int mode
     }
     if (DIM == 5) x2[4] = clampf(x2[4], (float)(-360.0 + 2 * kEpsS), (float)(360.0 - 2 * kEpsS));  // the two clamps of :256-258
     PlanarPair q;
-    lean_front<VARIANT, DIM, false>(x1, x2, edge, q);
+    lean_front<VARIANT, DIM, false, true, PRE>(x1, x2, edge, q, nullptr, pre1, pre2);
     // ---- stage 2: boundary integral of the two rectangles (P at the origin, T at (dx, dy)) ----
     const float kBig = 1e18f;
     const float ic = fminf(fmaxf(fast_rcp(q.c), -kBig), kBig), is = fminf(fmaxf(fast_rcp(q.s), -kBig), kBig);

@@ -382,6 +382,11 @@ __global__ __launch_bounds__(kBlock, ARC ? 8 : 4) void iou_pairwise_compact_kern
     __shared__ float4 row_cull[kPwRows];
     __shared__ int2 stack[kBlock / 64][kQCap];
     __shared__ int leftover[kBlock / 64];
+    // sin / cos of every box's jittered colatitude, once per box instead of once per surviving pair (two of the three
+    // sincos of a finishing pass): rows by their first threads, columns by their owner; the finishing lane — any lane,
+    // the survivors are compacted — reads them by index
+    __shared__ ColatTrig row_trig[kPwRows];
+    __shared__ ColatTrig col_trig[kBlock];
     const int edge = ARC ? (int)EDGE_ARC : edge_arg;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = blockIdx.y * rows_per_wg, rows = (m - r0 < rows_per_wg) ? m - r0 : rows_per_wg;
@@ -392,12 +397,14 @@ __global__ __launch_bounds__(kBlock, ARC ? 8 : 4) void iou_pairwise_compact_kern
 #pragma unroll
         for (int k = 0; k < 5; k++) row_raw[threadIdx.x][k] = g[k];
         row_cull[threadIdx.x] = make_float4(cg.s, cg.c, cg.th_rev, cg.r);
+        row_trig[threadIdx.x] = colat_trig(g[1], 1);
     }
-    __syncthreads();
     const int j = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = j < n;
     float a[5] = {0.0f, 0.0f, 1.0f, 1.0f, 0.0f};
     if (valid) load_box<DIM>(b2, j, a);
+    col_trig[threadIdx.x] = colat_trig(a[1], 2);
+    __syncthreads();
     const CullBox ca = cull_box(a, edge);
     int2* st = stack[wave];
     int count = 0;
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(kBlock, ARC ? 8 : 4) void iou_pairwise_compact_kern
 #pragma unroll
         for (int k = 0; k < 5; k++) g[k] = row_raw[e.x][k];
         load_box<DIM>(b2, e.y, p);
-        out[(int64_t)(r0 + e.x) * n + e.y] = lean_finish<VARIANT, DIM>(g, p, mode, edge);
+        out[(int64_t)(r0 + e.x) * n + e.y] = lean_finish<VARIANT, DIM, true>(g, p, mode, edge, row_trig[e.x], col_trig[e.y - blockIdx.x * kBlock]);
     };
     float* orow = out + (int64_t)r0 * n + j;   // this column's element of the tile's first row
     for (int i = 0; i < rows; i++) {
