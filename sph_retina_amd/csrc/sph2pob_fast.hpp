@@ -457,8 +457,9 @@ SPH_DEV ColatTrig colat_trig(float phi_deg, int role) {
     return t;
 }
 
-// PRE: the colatitude trig of the two boxes is handed in (`pre1`, `pre2`: exactly what the function would compute)
-template <int VARIANT, int DIM, bool GATES, bool CLAMPED = true, bool PRE = false>
+// PRE = 1: the colatitude trig of the two boxes is handed in (`pre1`, `pre2`: exactly what the function would compute);
+// PRE = 2: that of the first box only (one box against many: an NMS row)
+template <int VARIANT, int DIM, bool GATES, bool CLAMPED = true, int PRE = 0>
 SPH_DEV void lean_front(const float (&x1)[5], const float (&x2)[5], int edge, PlanarPair& o, FastTrig* trig = nullptr,
                         ColatTrig pre1 = ColatTrig{0.0f, 1.0f}, ColatTrig pre2 = ColatTrig{0.0f, 1.0f}) {
     const float e = (float)kEpsS, ea = (float)kEpsA;
@@ -469,8 +470,8 @@ SPH_DEV void lean_front(const float (&x1)[5], const float (&x2)[5], int edge, Pl
     float wp = edge_length(x2[2] * kDeg2Rad, edge), hp = edge_length(x2[3] * kDeg2Rad, edge);
     float sg, cg, sp, cp, sD, h2;   // sD = sin(theta_p - theta_g), h2 = 1 - cos(theta_p - theta_g)
     if (CLAMPED) {
-        if (PRE) { sg = pre1.s; cg = pre1.c; sp = pre2.s; cp = pre2.c; }
-        else { sincos_colat(phg, sg, cg); sincos_colat(php, sp, cp); }
+        if (PRE) { sg = pre1.s; cg = pre1.c; } else sincos_colat(phg, sg, cg);
+        if (PRE == 1) { sp = pre2.s; cp = pre2.c; } else sincos_colat(php, sp, cp);
         sin_vers_double(0.5f * (thp - thg), sD, h2);
     } else {
         float sh, ch;
@@ -611,7 +612,7 @@ SPH_DEV void lean_front(const float (&x1)[5], const float (&x2)[5], int edge, Pl
 // Spherical jitter + stages 1 + 2 for one pair that survived the cull: clamp(IoU, 0, 1).  The spherical jitter's shift
 // and the near-parallel safeguard are guarded like lean_front's rare branches.  A NaN coordinate gives NaN, as the
 // reference's torch.clamp chain does (sph_iou_api.py:86, :244-260).
-template <int VARIANT, int DIM, bool PRE = false>
+template <int VARIANT, int DIM, int PRE = 0>
 SPH_DEV float lean_finish(const float (&in1)[5], const float (&in2)[5], int mode, int edge, ColatTrig pre1 = ColatTrig{0.0f, 1.0f},
                           ColatTrig pre2 = ColatTrig{0.0f, 1.0f}) {
     const float e = (float)kEpsS, e2 = (float)(2 * kEpsS);
@@ -633,7 +634,7 @@ SPH_DEV float lean_finish(const float (&in1)[5], const float (&in2)[5], int mode
         const float sh1 = similar ? e2 : 0.0f, sh2 = similar ? e : 0.0f;  // x - 0 == x exactly
 #pragma unroll
         for (int k = 0; k < DIM; k++) { x1[k] = x1[k] - sh1; x2[k] = x2[k] + sh2; }
-        if (PRE && similar) { pre1 = colat_trig(x1[1], 1); pre2 = colat_trig(x2[1], 2); }   // the shifted colatitudes
+        if (PRE && similar) { pre1 = colat_trig(x1[1], 1); if (PRE == 1) pre2 = colat_trig(x2[1], 2); }   // the shifted colatitudes
     }
     x1[0] = clampf(x1[0], e2, (float)(360.0 - kEpsS));
     x2[0] = clampf(x2[0], e, (float)(360.0 - 2 * kEpsS));

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(kBlock, ARC ? 8 : 4) void iou_pairwise_compact_kern
 #pragma unroll
         for (int k = 0; k < 5; k++) g[k] = row_raw[e.x][k];
         load_box<DIM>(b2, e.y, p);
-        out[(int64_t)(r0 + e.x) * n + e.y] = lean_finish<VARIANT, DIM, true>(g, p, mode, edge, row_trig[e.x], col_trig[e.y - blockIdx.x * kBlock]);
+        out[(int64_t)(r0 + e.x) * n + e.y] = lean_finish<VARIANT, DIM, 1>(g, p, mode, edge, row_trig[e.x], col_trig[e.y - blockIdx.x * kBlock]);
     };
     float* orow = out + (int64_t)r0 * n + j;   // this column's element of the tile's first row
     for (int i = 0; i < rows; i++) {
@@ -777,12 +777,13 @@ __global__ __launch_bounds__(kBlock) void nms_mask_compact_kernel(const float* _
         float x[5];
         load_box<DIM>(boxes, i, x);
         const CullBox cx = cull_box(x, EDGE_ARC);
+        const ColatTrig xt = colat_trig(x[1], 1);   // the row's colatitude trig: once per row, not once per surviving pair
         int* st = stack[wave];
         int count = 0;
         auto finish_one = [&](int j) {
             float y[5];
             load_box<DIM>(boxes, j, y);
-            if (lean_finish<VARIANT, DIM>(x, y, MODE_IOU, EDGE_ARC) > thr) {
+            if (lean_finish<VARIANT, DIM, 2>(x, y, MODE_IOU, EDGE_ARC, xt) > thr) {
                 const int rel = j - (int)(base << 6);
                 atomicOr(&bm[rel >> 5], 1u << (rel & 31));
             }
