@@ -109,3 +109,24 @@ def test_pairwise_tiles_with_merged_leftovers_match_aligned_bit_for_bit(dim, edg
             pw = S.sph2pob_standard_iou(t1, t2, rbb_edge=edge)
             al = S.sph2pob_standard_iou(t1.repeat_interleave(n, 0), t2.repeat(m, 1), is_aligned=True, rbb_edge=edge)
             assert torch.equal(pw.reshape(-1), al)
+
+
+def test_independent_calls_on_two_streams_give_the_same_bits():
+    """calls that do not depend on each other may be issued on several HIP streams (their ramp-up and
+    tail overlap); the launchers keep no state between calls, so the results are those of one stream"""
+    import torch
+    import sph_retina_amd as S
+    from oracle import oracle as O
+    n = 300_000
+    sets = [(torch.from_numpy(O.generate_boxes(n, 40 + k)).cuda(), torch.from_numpy(O.generate_boxes(n, 50 + k)).cuda()) for k in range(4)]
+    want = [S.sph2pob_standard_iou(a, b, is_aligned=True) for a, b in sets]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = [None] * 4
+    for rep in range(20):
+        for k, (a, b) in enumerate(sets):
+            with torch.cuda.stream(streams[k & 1]):
+                got[k] = S.sph2pob_standard_iou(a, b, is_aligned=True)
+    torch.cuda.synchronize()
+    for k in range(4):
+        assert torch.equal(got[k], want[k])
