@@ -130,3 +130,44 @@ def test_independent_calls_on_two_streams_give_the_same_bits():
     torch.cuda.synchronize()
     for k in range(4):
         assert torch.equal(got[k], want[k])
+
+
+@pytest.mark.parametrize('dim', [4, 5])
+def test_out_of_range_coordinates_are_clamped_like_the_reference_never_culled_wrongly(dim):
+    """The cull tests the coordinates' ranges on their bit patterns and leaves any pair with a coordinate outside the
+    range the spherical jitter clamps to (theta [0, 360], phi / alpha / beta [0, 180]; sph_iou_api.py:244-260) to the
+    finishing stage, which clamps exactly like the reference: the result must be the one of the pre-clamped boxes."""
+    import torch
+    import sph_retina_amd as S
+    from oracle import oracle as O
+    n = 40000
+    box = 'rbfov' if dim == 5 else 'bfov'
+    b1, b2 = O.generate_boxes(n, 61, box=box), O.generate_boxes(n, 62, box=box)
+    b2[: n // 2] = b1[: n // 2] + np.random.default_rng(3).standard_normal((n // 2, dim)).astype(np.float32) * 3
+    b2[:, 0] %= 360.0
+    b2[:, 1:4] = b2[:, 1:4].clip(1, 179)   # the partner of an out-of-range box is in range (see below)
+    rng = np.random.default_rng(4)
+    bad1, bad2 = b1.copy(), b2.copy()
+    # one box of a pair at a time (even rows: the first, odd rows: the second): were both out of range on the same side
+    # they would be EQUAL after clamping, and the jitter's `similar` test — taken on the raw values — would differ
+    for arr, parity in ((bad1, 0), (bad2, 1)):
+        rows = rng.integers(0, n // 2, 6000) * 2 + parity
+        cols = rng.integers(0, 4, 6000)
+        vals = rng.choice(np.array([-50.0, -0.5, -1e-3, 180.5, 250.0, 361.0, 720.0, 1e6, -1e6], dtype=np.float32), 6000)
+        arr[rows, cols] = vals
+    hi = np.array([360.0, 180.0, 180.0, 180.0] + ([np.inf] if dim == 5 else []), dtype=np.float32)
+    lo = np.array([0.0, 0.0, 0.0, 0.0] + ([-np.inf] if dim == 5 else []), dtype=np.float32)
+    ok1, ok2 = np.clip(bad1, lo, hi), np.clip(bad2, lo, hi)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    for fn in (S.sph2pob_standard_iou, S.sph2pob_efficient_iou):
+        got = fn(t(bad1), t(bad2), is_aligned=True)
+        want = fn(t(ok1), t(ok2), is_aligned=True)
+        assert torch.equal(got, want), fn.__name__
+        pw = fn(t(bad1[:9]), t(bad2[:700]))
+        assert torch.equal(pw, fn(t(ok1[:9]), t(ok2[:700])))
+    # and against the oracle (which restates the reference's clamps) on the out-of-range rows
+    rows = np.unique(np.nonzero((bad1 != b1).any(1) | (bad2 != b2).any(1))[0])[:3000]
+    want = O.iou_aligned(bad1[rows], bad2[rows], 'standard', planar='exact', dtype=np.float64)
+    got = S.sph2pob_standard_iou(t(bad1[rows]), t(bad2[rows]), is_aligned=True).cpu().numpy()
+    d = np.abs(got - want)
+    assert np.mean(d) < 1e-6 and (d > 1e-4).sum() <= 3
