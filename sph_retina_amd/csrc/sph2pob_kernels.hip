@@ -39,6 +39,7 @@ static bool g_prefetch = getenv("SPH2POB_NO_PREFETCH") == nullptr;
 static int g_pw_rows = getenv("SPH2POB_PW_ROWS") ? atoi(getenv("SPH2POB_PW_ROWS")) : 0;
 static int g_slices_per_wave = getenv("SPH2POB_SLICES_PER_WAVE") ? atoi(getenv("SPH2POB_SLICES_PER_WAVE")) : 0;
 static int g_wgs_per_cu = getenv("SPH2POB_WGS_PER_CU") ? atoi(getenv("SPH2POB_WGS_PER_CU")) : 0;
+static bool g_no_prio = getenv("SPH2POB_NO_PRIO") != nullptr;   // A/B: no wave priority in the chunk kernel
 static bool g_persistent = getenv("SPH2POB_ALIGNED_KERNEL") != nullptr && getenv("SPH2POB_ALIGNED_KERNEL")[0] == 'p';   // A/B: the persistent form
 
 template <int DIM>
@@ -301,6 +302,15 @@ __global__ __launch_bounds__(64 * WAVES, DIM == 4 ? 8 : 7) void iou_aligned_chun
 #if defined(SPH_STAMPS)
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
 #endif
+    // Wave priority.  The SIMD's arbiter serves the oldest wave first, so a wave whose boxes arrive late waits for its
+    // cheap cull behind the finishing passes of the waves that got theirs early, and its own pass starts that much later:
+    // the tail of a launch whose waves are all resident at once.  The load + cull phase runs at priority 1, the finishing
+    // pass at 0 (any level above the pass's does the same): 7.76 -> 7.28 us per 1 M pairs, 12.3 -> 11.8 at 1.5 M, 5.21 -> 5.02
+    // at 500 k, 11.66 -> 11.17 for 1 M nearby pairs; from 3 M pairs up, where workgroups start as others retire, it costs
+    // 1-2.5 % instead (2.6 M: +2.8 %), and RBFoV launches lose 2.5 % at 1 M: the launcher asks for it for BFoV launches of
+    // up to two rounds (profiles/r03g_ab_prio*.log).
+    const bool cull_first = (edge_arg & 0x10000) != 0;
+    if (cull_first) __builtin_amdgcn_s_setprio(1);
     // BFoV: lanes past the end of the batch load the last pair again (never stored, never stacked): no zero fill of the
     // sixteen registers, no branch around the loads (8.31 -> 8.24 us per 1 M pairs; RBFoV's twenty dword loads were faster
     // behind the branch: 10.5 vs 10.7 us)
@@ -344,6 +354,7 @@ __global__ __launch_bounds__(64 * WAVES, DIM == 4 ? 8 : 7) void iou_aligned_chun
     SPH_STAMP(3);
     SPH_STAMP_VALUE((unsigned long long)count);
     wave_lds_fence();
+    if (cull_first) __builtin_amdgcn_s_setprio(0);
     for (int b = 0; b < count; b += 64) {
         const int slot = b + lane;
         if (slot < count) {
@@ -1112,6 +1123,8 @@ struct AlignedLaunch {
 #define SPH_PIPE(PF, ARC, REF) hipLaunchKernelGGL((iou_aligned_compact_kernel<VV, D, PF, ARC, REF>), dim3((unsigned)wgs), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge_k)
             if (!ref_finish && V < 2 && !g_persistent) {   // the default: one-round chunk kernel
                 const unsigned cw = (unsigned)((n + kBlock * kChunkSlices - 1) / (kBlock * kChunkSlices));
+                // cull phase at a higher wave priority while (nearly) the whole grid is resident at once: see the kernel
+                const int edge_k = (edge | (angle << 8)) | (D == 4 && (int64_t)cw <= kCUs * 8 * 2 && !g_no_prio ? 0x10000 : 0);
                 if (edge == SPH2POB_EDGE_ARC) hipLaunchKernelGGL((iou_aligned_chunk_kernel<VV, D, true, kChunkSlices>), dim3(cw), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge_k);
                 else hipLaunchKernelGGL((iou_aligned_chunk_kernel<VV, D, false, kChunkSlices>), dim3(cw), dim3(kBlock), 0, s, b1, b2, out, (int)n, mode, edge_k);
             } else
