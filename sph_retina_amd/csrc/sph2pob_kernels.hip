@@ -426,7 +426,8 @@ __global__ __launch_bounds__(kBlock, ARC ? 8 : 4) void iou_pairwise_compact_kern
         load_box<DIM>(b2, e.y, p);
         out[(int64_t)(r0 + e.x) * n + e.y] = lean_finish<VARIANT, DIM, 1>(g, p, mode, edge, row_trig[e.x], col_trig[e.y - blockIdx.x * kBlock]);
     };
-    float* orow = out + (int64_t)r0 * n + j;   // this column's element of the tile's first row
+    float* orow = out + (int64_t)r0 * n + j;   // this column's element of the tile's first row (cull rows at a higher
+                                               // wave priority than the passes, as in the chunk kernel: no gain here)
     for (int i = 0; i < rows; i++) {
         const float4 rc = row_cull[i];
         const bool culled = cull_pair(CullBox{rc.x, rc.y, rc.z, rc.w}, ca), surv = valid & !culled;
