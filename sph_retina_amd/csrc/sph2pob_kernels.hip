@@ -308,7 +308,8 @@ __global__ __launch_bounds__(64 * WAVES, DIM == 4 ? 8 : 7) void iou_aligned_chun
     // pass at 0 (any level above the pass's does the same): 7.76 -> 7.28 us per 1 M pairs, 12.3 -> 11.8 at 1.5 M, 5.21 -> 5.02
     // at 500 k, 11.66 -> 11.17 for 1 M nearby pairs; from 3 M pairs up, where workgroups start as others retire, it costs
     // 1-2.5 % instead (2.6 M: +2.8 %), and RBFoV launches lose 2.5 % at 1 M: the launcher asks for it for BFoV launches of
-    // up to two rounds (profiles/r03g_ab_prio*.log).
+    // up to two rounds (profiles/r03g_ab_prio*.log).  A priority that falls (or rises) with the wave's progress through
+    // its pass, to keep the waves of a SIMD in step (or to retire them one by one): 7.70 / 7.55 against 7.31 / 7.18 us.
     const bool cull_first = (edge_arg & 0x10000) != 0;
     if (cull_first) __builtin_amdgcn_s_setprio(1);
     // BFoV: lanes past the end of the batch load the last pair again (never stored, never stacked): no zero fill of the
