@@ -275,7 +275,8 @@ __global__ __launch_bounds__(kBlock, REF ? 4 : (DIM == 4 ? 7 : 5)) void iou_alig
 //   * pooling the survivors of 4 / 8 / 16 waves in one workgroup-wide stack (one ds_add_rtn per wave, one LDS-only
 //     barrier, chunks assigned or claimed from a counter) so that all passes but one per workgroup are full: 12 % fewer
 //     finishing instructions at 8 waves and NO gain (8.8-8.95 us at 1 M, 55-57 at 8 M; r02l_ab_pool_*.log) — the
-//     barrier couples waves that sit on different SIMDs; built, measured, removed;
+//     barrier couples waves that sit on different SIMDs; built, measured, removed (and again with the cull phase at a
+//     raised wave priority: 7.19 vs 7.29 us at 1 M, 15.5 vs 14.9 at 2 M, 49.5 vs 47.2 at 8 M: r03j_ab_pool_prio_*.log);
 //   * workgroups of 1 / 2 / 4 / 8 / 16 independent waves: the same within 1 % from 100 k to 8 M pairs (16: +3 %;
 //     r02z_ab_wg*.log); 4 stays;
 //   * rotating which wave of the persistent form takes which leftover chunk: the hardware already rotates the
