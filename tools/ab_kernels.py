@@ -29,6 +29,7 @@ def main():
     ap.add_argument('--rounds', type=int, default=5)
     ap.add_argument('--launches', type=int, default=1000)
     ap.add_argument('--settle', type=int, default=3000)
+    ap.add_argument('--reference-order', action='store_true', help="the reference's fp32 operation order (SPH2POB_FLAG_REFERENCE_ORDER)")
     ap.add_argument('--nearby', type=float, default=0.0, help='sigma (deg) of box2 = box1 + noise; 0 = independent uniform boxes')
     ap.add_argument('arms', nargs='+')
     args = ap.parse_args()
@@ -58,7 +59,7 @@ def main():
         fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64] + [ctypes.c_int] * 5 + [ctypes.c_void_p]
         fn.restype = ctypes.c_int
         arms.append((label, fn))
-    variant = {'standard': 0, 'efficient': 1}[args.variant]
+    variant = {'standard': 0, 'efficient': 1, 'legacy': 2}[args.variant] | (0x100 if args.reference_order else 0)
     stream = torch.cuda.current_stream(dev)
     sp = ctypes.c_void_p(stream.cuda_stream)
     for n in [int(x) for x in args.pairs.split(',')]:
