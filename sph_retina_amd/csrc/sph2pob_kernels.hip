@@ -939,7 +939,9 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 }
 
 // A: one thread per column (anchor): running max / first argmax over the k rows, and per-wave row partials.
-// Rows are taken 32 at a time: 32 independent coalesced loads per lane, then a transposing butterfly — at the stage
+// Rows are taken 32 at a time: 32 independent coalesced loads per lane (unconditional, on clamped addresses, into a
+// register array: written as `live ? ov[..] : -inf` each load sat behind its own branch and its own wait — 64 serial
+// round trips per lane, 20 us instead of 9 for 64 x 98 208), then a transposing butterfly — at the stage
 // with lane mask M a lane keeps the lower (bit clear) or upper (bit set) half of its rows and receives the partner's
 // copy of that half — leaves lane L with the wave-wide maximum key of row (L >> 1) after 31 + 1 exchanges, instead of
 // one 6-step wave reduction per row (192 exchanges per 32 rows).
@@ -952,17 +954,23 @@ __global__ __launch_bounds__(kBlock) void assign_cols_kernel(const float* __rest
     const int part = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const bool valid = j < n;
     const int64_t jc = valid ? j : n - 1;   // clamp the address, mask the value
+    const unsigned long long lane_mask = valid ? ~0ull : 0ull;   // a mask, not a select: selects here compile to 32 branches
     float best = -__builtin_inff();
     int besti = 0;
     for (int r0 = 0; r0 < k; r0 += kAssignRows) {
         unsigned long long key[kAssignRows];
+        float raw[kAssignRows];
+#pragma unroll
+        for (int t = 0; t < kAssignRows; t++)   // unconditional (clamped addresses): all 32 loads are issued before the first wait
+            raw[t] = ov[(int64_t)(r0 + t < k ? r0 + t : k - 1) * n + jc];
 #pragma unroll
         for (int t = 0; t < kAssignRows; t++) {
             const int i = r0 + t;
-            const bool live = valid && i < k;
-            const float v = live ? ov[(int64_t)(i < k ? i : k - 1) * n + jc] : -__builtin_inff();
-            if (v > best) { best = v; besti = i; }
-            key[t] = live ? pack_max_key(v, j) : 0ull;
+            const float v = (valid && i < k) ? raw[t] : -__builtin_inff();
+            const bool up = v > best;
+            best = up ? v : best;
+            besti = up ? i : besti;
+            key[t] = pack_max_key(v, j) & lane_mask;   // rows past k are reduced but never written
         }
 #pragma unroll
         for (int cnt = kAssignRows, m = 32; cnt > 1; cnt >>= 1, m >>= 1) {
@@ -989,9 +997,15 @@ __global__ __launch_bounds__(kBlock) void assign_rows_kernel(const unsigned long
     __shared__ unsigned long long sm[kBlock / 64];
     const int i = blockIdx.x;
     unsigned long long best = 0ull;
-    for (int p = threadIdx.x; p < nparts; p += kBlock) {
-        unsigned long long v = partial[(int64_t)i * nparts + p];
-        best = v > best ? v : best;
+    for (int p0 = threadIdx.x; p0 < nparts; p0 += kBlock * 8) {   // 8 independent loads per round (a repeated last partial changes no maximum)
+        unsigned long long v[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const int p = p0 + t * kBlock;
+            v[t] = partial[(int64_t)i * nparts + (p < nparts ? p : nparts - 1)];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; t++) best = v[t] > best ? v[t] : best;
     }
     best = wave_max_u64(best);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = best;
@@ -1014,24 +1028,37 @@ __global__ __launch_bounds__(kBlock) void assign_finalize_kernel(const float* __
                                                                 const int64_t* __restrict__ gt_labels,
                                                                 int64_t* __restrict__ gt_inds,
                                                                 int64_t* __restrict__ labels) {
-    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (j >= n) return;
+    const int64_t jraw = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = jraw < n;
+    const int64_t j = valid ? jraw : n - 1;   // lanes past the end stay in the wave (v_readlane below reads lanes 0..31) and store nothing
     const float m = max_ov[j];
+    const int64_t am = argmax_ov[j];   // unconditional: one round trip for both, not two
     int64_t a = -1;
     if (m >= neg_lo && m < neg_hi) a = 0;
-    if (m >= pos_thr) a = argmax_ov[j] + 1;
+    if (m >= pos_thr) a = am + 1;
     if (low_quality) {
-        if (assign_all) {   // the column is re-read: keep 8 independent loads in flight
-#pragma unroll 8
-            for (int i = 0; i < k; i++) {
-                const float g = gt_max[i];
-                if (ov[(int64_t)i * n + j] == g && g >= min_pos) a = i + 1;
+        if (assign_all) {   // the column is re-read, 32 rows at a time: unconditional (clamped) loads, all issued before the first wait
+            for (int r0 = 0; r0 < k; r0 += kAssignRows) {
+                float raw[kAssignRows];
+#pragma unroll
+                for (int t = 0; t < kAssignRows; t++) raw[t] = ov[(int64_t)(r0 + t < k ? r0 + t : k - 1) * n + j];
+                // the 32 row maxima of this round in one vector load (lane t holds row r0 + t), handed out with v_readlane;
+                // a row past k or below min_pos becomes NaN, which equals nothing
+                const int il = r0 + (int)(threadIdx.x & (kAssignRows - 1));
+                const float gl = gt_max[il < k ? il : k - 1];
+                const int gbits = __float_as_int((il < k && gl >= min_pos) ? gl : __builtin_nanf(""));
+#pragma unroll
+                for (int t = 0; t < kAssignRows; t++) {
+                    const float g = __int_as_float(__builtin_amdgcn_readlane(gbits, t));
+                    a = raw[t] == g ? r0 + t + 1 : a;
+                }
             }
         } else {
             for (int i = 0; i < k; i++)
                 if (gt_max[i] >= min_pos && gt_argmax[i] == j) a = i + 1;
         }
     }
+    if (!valid) return;
     gt_inds[j] = a;
     if (labels) labels[j] = a > 0 ? gt_labels[a - 1] : -1;
 }
