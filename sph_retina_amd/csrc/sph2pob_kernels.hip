@@ -682,8 +682,20 @@ __global__ __launch_bounds__(kBlock) void sum_pass1(const float* __restrict__ x,
 }
 __global__ __launch_bounds__(kBlock) void sum_pass2(const float* __restrict__ ws, int nb, float scale,
                                                    float* __restrict__ out) {
+    // 16 loads per round on clamped indices, all in flight before the first add (a loop of load + add waits for every
+    // element: 1 M pairs leave 3 907 partials = 16 serial round trips per thread); the adds keep their order, a masked
+    // element adds +0
     float acc = 0.0f;
-    for (int i = threadIdx.x; i < nb; i += kBlock) acc += ws[i];
+    for (int i0 = threadIdx.x; i0 < nb; i0 += kBlock * 16) {
+        float v[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int i = i0 + t * kBlock;
+            v[t] = ws[i < nb ? i : nb - 1];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t++) acc += (i0 + t * kBlock < nb) ? v[t] : 0.0f;
+    }
     float r = block_sum(acc);
     if (threadIdx.x == 0) out[0] = r * scale;
 }
