@@ -514,10 +514,13 @@ template <int DIM>
 __device__ __forceinline__ float element_weight(const float* __restrict__ w, int wd, int64_t i) {
     if (!w) return 1.0f;
     if (wd == 1) return w[i];
-    float s = 0.0f;
-    for (int k = 0; k < wd; k++) s += w[i * wd + k];
-    if (DIM == 4 && wd == 4) return (s + s / 4.0f) / 5.0f;
-    return s / (float)wd;
+    float v[DIM], s = 0.0f;   // wd == DIM here (the launchers reject anything else): DIM loads in flight, not a loop of load + wait
+#pragma unroll
+    for (int k = 0; k < DIM; k++) v[k] = w[i * DIM + k];
+#pragma unroll
+    for (int k = 0; k < DIM; k++) s += v[k];
+    if (DIM == 4) return (s + s / 4.0f) / 5.0f;
+    return s / (float)DIM;
 }
 
 // waves per SIMD the loss kernels that carry the adjoint are compiled for (closed-form front end): 4 = ~105 VGPRs, no
@@ -655,6 +658,7 @@ __global__ __launch_bounds__(kBlock) void grad_scale_kernel(const float* stash, 
     // one scalar load per workgroup instead of a 40 MB pass (the stash tensor itself is handed to autograd).  The grid is
     // capped and strided so that this early exit costs a small launch, not the dispatch of 20 000 workgroups.
     if (stride == 0 && out == stash && g[0] == 1.0f) return;
+    // (four elements in flight per lane instead of one: measured, no gain — the 40 MB pass is bandwidth-bound; r03p_ab_loss.log)
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock)
         out[e] = stash[e] * g[stride ? (e / dim) : 0];
 }
