@@ -957,7 +957,9 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 // A: one thread per column (anchor): running max / first argmax over the k rows, and per-wave row partials.
 // Rows are taken 32 at a time: 32 independent coalesced loads per lane (unconditional, on clamped addresses, into a
 // register array: written as `live ? ov[..] : -inf` each load sat behind its own branch and its own wait — 64 serial
-// round trips per lane, 20 us instead of 9 for 64 x 98 208), then a transposing butterfly — at the stage
+// round trips per lane, 20 us instead of 9 for 64 x 98 208; requesting the NEXT round's 32 before this round's butterfly
+// was measured too: 18.1 -> 17.4 us for the three kernels at 98 208 anchors, 41.2 -> 44.9 us at 392 832, not kept:
+// r03r_ab_assign.log), then a transposing butterfly — at the stage
 // with lane mask M a lane keeps the lower (bit clear) or upper (bit set) half of its rows and receives the partner's
 // copy of that half — leaves lane L with the wave-wide maximum key of row (L >> 1) after 31 + 1 exchanges, instead of
 // one 6-step wave reduction per row (192 exchanges per 32 rows).
