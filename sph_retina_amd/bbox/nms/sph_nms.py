@@ -91,11 +91,12 @@ def sph_batched_nms(boxes, scores, idxs, nms_cfg, iou_calculator='efficient', cl
     order = by_score[torch.argsort(idxs[by_score], stable=True)]
     flags = _nms_sorted(G.as_f32(boxes[order]), idxs[order].to(torch.int64).contiguous(), float(iou_threshold),
                         _variant_of(iou_calculator))
-    total_mask = torch.zeros(scores.shape, dtype=torch.bool, device=scores.device)
+    # the reference takes the kept original indices in ascending order (:49) and sorts them by descending score (:50-51);
+    # a stable sort breaks ties by that ascending index — which is the order `by_score` already has, so the kept entries
+    # of `by_score` ARE that list: one scatter + one masked gather instead of nonzero + gather + a third sort
+    total_mask = torch.empty(scores.shape, dtype=torch.bool, device=scores.device)
     total_mask[order] = flags.bool()
-    keep = total_mask.nonzero(as_tuple=False).view(-1)           # ascending original index (reference :49)
-    inds = torch.argsort(scores[keep], descending=True, stable=True)
-    keep = keep[inds][:max_num]
+    keep = by_score[total_mask[by_score]][:max_num]
     dets = torch.cat([boxes[keep], scores[keep][:, None]], -1)
     return dets, keep
 
