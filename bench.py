@@ -28,7 +28,7 @@ over ranks.
 Extra objects on the JSON line:
   roofline      the dominant kernel (iou_aligned_chunk_kernel) against the HBM roofline: algorithmic bytes = 36 B/pair
                 (2 x 16 B boxes in + 4 B IoU out) / average launch duration measured here with HIP events
-                on the launch stream (`rocprof_traced_kernel_ms`: the committed rocprofv3 kernel-trace average of the same
+                on the launch stream, median of 5 runs of K/5 back-to-back launches (`rocprof_traced_kernel_ms`: the committed rocprofv3 kernel-trace average of the same
                 command, which is 1-1.5 us higher: the tracer brackets every dispatch).  `traffic` (PMC-measured HBM bytes
                 per launch) and `valu_active_frac` come from
                 this round's committed rocprofv3 summary (separate --pmc passes) and are only attached when this run's
@@ -194,6 +194,10 @@ def main(argv=None):
     import torch.distributed as dist
     from sph_retina_amd import _lib, _torch_glue as G
     dry = args.dry_run
+    # host-side tensor work here is only the synthetic boxes' RNG: torch sizes its CPU pool by the cores it SEES (128 on a
+    # GPU box) while the box grants a share of them; an oversubscribed pool runs into the cgroup's CPU quota and the
+    # launching thread is stalled with it (seen as one ~60 ms hole in a later measurement)
+    torch.set_num_threads(min(torch.get_num_threads(), 8))
     if not dry:
         if rank == 0:
             _lib.build()   # no-op when sph_retina_amd/lib/libsph2pob_hip.so is up to date
@@ -316,14 +320,20 @@ def main(argv=None):
             ev1.record(stream)
             torch.cuda.synchronize(dev)
             return ev0.elapsed_time(ev1) / reps
+        def median_ms(fn, reps, segments=5):
+            """median over `segments` event-timed runs of `reps` launches: one host stall (the launching thread losing
+            its CPU for a scheduler period) lands in one segment instead of in the figure"""
+            return sorted(events_ms(fn, reps) for _ in range(segments))[segments // 2]
         # dominant-kernel duration: HIP events on the launch stream around back-to-back launches (no collective)
-        kernel_ms = events_ms(lambda r: kernel(b1, b2, shards[0], n), max(args.steps, 1000))
+        kernel_ms = median_ms(lambda r: kernel(b1, b2, shards[0], n), max(args.steps // 5, 200))
         if rank == 0 and extras:
             m1 = PAIRS_ONE_GPU
             sets = [(make_boxes(m1, 100 + 2 * k, dev), make_boxes(m1, 101 + 2 * k, dev),
                      torch.empty(m1, dtype=torch.float32, device=dev)) for k in range(COLD_SETS)]
+            torch.cuda.synchronize(dev)
+            time.sleep(0.2)   # the CPU pool that drew the boxes goes to sleep before the launch loop needs its core
             events_ms(lambda r: kernel(*sets[r % COLD_SETS], m1), 500)
-            t = events_ms(lambda r: kernel(*sets[r % COLD_SETS], m1), 2000)
+            t = median_ms(lambda r: kernel(*sets[r % COLD_SETS], m1), 500)
             gbs = BYTES_PER_PAIR * m1 / (t * 1e-3) / 1e9
             cold = {'pairs': m1, 'distinct_sets': COLD_SETS, 'working_set_bytes': COLD_SETS * BYTES_PER_PAIR * m1,
                     'kernel_ms': t, 'achieved': gbs, 'frac': gbs / HBM_PEAK_GBS}
