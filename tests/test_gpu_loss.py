@@ -365,3 +365,43 @@ def test_backward_twice_and_non_unit_upstream_gradients(L, reduction):
     assert torch.equal(stash, keep)
     assert lib.sph2pob_loss_grad_scale_f32(stash.data_ptr(), two.data_ptr(), 0, stash.data_ptr(), 1000, 5, st) == 0
     assert torch.equal(stash, keep * 2)
+
+
+def test_final_sum_round_boundaries_and_weight_means(L):
+    """The one workgroup that adds the per-workgroup partials takes them 16 x 256 at a time (masked past the end): batch
+    sizes whose partial counts sit on either side of a round (1, 255, 256, 257, 4095, 4096, 4097, 9000 partials) must give
+    the float64 sum of the elements within float rounding, twice the same bits; and an (n, 4) weight is its row mean
+    (sph2pob_iou_loss.py:48), equal to passing that mean as an (n,) weight."""
+    from sph_retina_amd import _lib
+    lib = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device='cpu').manual_seed(7)
+    nmax = 9000 * 256
+    u = torch.rand((nmax, 4), generator=g)
+    tgt = torch.stack([u[:, 0] * 360, 10 + u[:, 1] * 160, 5 + u[:, 2] * 60, 5 + u[:, 3] * 60], 1).cuda()
+    pred = (tgt + torch.randn((nmax, 4), generator=g).cuda() * 3).contiguous()
+    pred[:, 1].clamp_(1, 179)
+    pred[:, 2:].clamp_(1, 120)
+    ws = torch.empty(int(lib.sph2pob_loss_sum_workspace_floats(nmax)), device='cuda')
+    for nb in (1, 255, 256, 257, 4095, 4096, 4097, 9000):
+        n = nb * 256 - 3
+        e = torch.empty(n, device='cuda')
+        s1, s2, s3 = (torch.empty((), device='cuda') for _ in range(3))
+        gp = torch.empty((n, 4), device='cuda')
+        assert lib.sph2pob_loss_fwd_f32(pred.data_ptr(), tgt.data_ptr(), None, 0, 1.0, e.data_ptr(), None, n, 4, 3, 1e-6, st) == 0
+        assert lib.sph2pob_loss_fwd_sum_f32(pred.data_ptr(), tgt.data_ptr(), None, 0, 1.0, s1.data_ptr(), ws.data_ptr(), n, 4, 3, 1e-6, st) == 0
+        assert lib.sph2pob_loss_fwd_sum_f32(pred.data_ptr(), tgt.data_ptr(), None, 0, 1.0, s2.data_ptr(), ws.data_ptr(), n, 4, 3, 1e-6, st) == 0
+        assert lib.sph2pob_loss_fwd_grad_f32(pred.data_ptr(), tgt.data_ptr(), None, 0, 1.0, None, s3.data_ptr(), ws.data_ptr(),
+                                             gp.data_ptr(), None, n, 4, 3, 1e-6, st) == 0
+        ref = float(e.double().sum())
+        assert torch.equal(s1, s2) and torch.equal(s1, s3), nb
+        assert abs(float(s1) - ref) < 2e-6 * ref, (nb, float(s1), ref)
+    n = 70001
+    w4 = torch.rand((n, 4), device='cuda') * (torch.rand((n, 1), device='cuda') > 0.5)
+    # the reference widens an (n, 4) weight to five columns with the row mean and takes the mean again (sph2pob_transform.py:32-34)
+    m = w4.mean(1)
+    w1 = ((w4.sum(1) + m) / 5.0).contiguous()
+    ea, eb = torch.empty(n, device='cuda'), torch.empty(n, device='cuda')
+    assert lib.sph2pob_loss_fwd_f32(pred.data_ptr(), tgt.data_ptr(), w4.data_ptr(), 4, 1.0, ea.data_ptr(), None, n, 4, 3, 1e-6, st) == 0
+    assert lib.sph2pob_loss_fwd_f32(pred.data_ptr(), tgt.data_ptr(), w1.data_ptr(), 1, 1.0, eb.data_ptr(), None, n, 4, 3, 1e-6, st) == 0
+    assert torch.allclose(ea, eb, rtol=1e-6, atol=0) and torch.equal(ea == 0, eb == 0)   # torch's mean adds in another order: a few ulps
