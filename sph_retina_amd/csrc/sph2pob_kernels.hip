@@ -402,7 +402,16 @@ __global__ __launch_bounds__(kBlock, ARC ? 8 : 4) void iou_pairwise_compact_kern
     __shared__ ColatTrig col_trig[kBlock];
     const int edge = ARC ? (int)EDGE_ARC : edge_arg;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r0 = blockIdx.y * rows_per_wg, rows = (m - r0 < rows_per_wg) ? m - r0 : rows_per_wg;
+    // dispatch order = LAST column tile first, all of its row chunks, then the tile before it: anchor grids end with their
+    // coarsest level (mmdet's AnchorGenerator walks the strides upwards) and their tiles grow heavier towards the end —
+    // the coarsest anchors survive the cull against nearly every GT and carry the longest serial chains of passes —, and
+    // the grid is larger than what is resident at once: dispatched last, the heaviest tiles started last.  Heaviest first:
+    // 64 x 98 208 anchors 21.7 -> 18.5 us, 64 x 392 832 47.2 -> 41.3 us with the rows-per-workgroup rule retuned for it
+    // (profiles/r03y_ab_pairwise*.log, r03z_ab_pairwise.log); tiles taken from both ends inwards instead: 20.2 / 42.1 us.
+    // A caller that lists the coarse level first gets the previous behaviour.
+    const unsigned lid = blockIdx.y * gridDim.x + blockIdx.x;
+    const int bx = (int)(gridDim.x - 1 - lid / gridDim.y), by = (int)(lid % gridDim.y);
+    const int r0 = by * rows_per_wg, rows = (m - r0 < rows_per_wg) ? m - r0 : rows_per_wg;
     if ((int)threadIdx.x < rows) {
         float g[5];
         load_box<DIM>(b1, r0 + threadIdx.x, g);
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(kBlock, ARC ? 8 : 4) void iou_pairwise_compact_kern
         row_cull[threadIdx.x] = make_float4(cg.s, cg.c, cg.th_rev, cg.r);
         row_trig[threadIdx.x] = colat_trig(g[1], 1);
     }
-    const int j = blockIdx.x * kBlock + threadIdx.x;
+    const int j = bx * kBlock + threadIdx.x;
     const bool valid = j < n;
     float a[5] = {0.0f, 0.0f, 1.0f, 1.0f, 0.0f};
     if (valid) load_box<DIM>(b2, j, a);
@@ -426,7 +435,7 @@ __global__ __launch_bounds__(kBlock, ARC ? 8 : 4) void iou_pairwise_compact_kern
 #pragma unroll
         for (int k = 0; k < 5; k++) g[k] = row_raw[e.x][k];
         load_box<DIM>(b2, e.y, p);
-        out[(int64_t)(r0 + e.x) * n + e.y] = lean_finish<VARIANT, DIM, 1>(g, p, mode, edge, row_trig[e.x], col_trig[e.y - blockIdx.x * kBlock]);
+        out[(int64_t)(r0 + e.x) * n + e.y] = lean_finish<VARIANT, DIM, 1>(g, p, mode, edge, row_trig[e.x], col_trig[e.y - bx * kBlock]);
     };
     float* orow = out + (int64_t)r0 * n + j;   // this column's element of the tile's first row (cull rows at a higher
                                                // wave priority than the passes, as in the chunk kernel: no gain here)
@@ -1195,14 +1204,16 @@ struct PairwiseLaunch {
         if (fast && V < 2 && angle == SPH2POB_ANGLE_EQUATOR && n < ((int64_t)1 << 31) - kBlock && m <= (int64_t)65535 * 4 &&
             !g_no_compact) {
             // rows per workgroup: enough to amortise the per-column setup and fill the survivor stacks, few enough that the
-            // grid holds thousands of workgroups (tools/sweep_pw_rows.sh, 64 GT: 98 208 anchors 27.6 us at 8 rows, 31.8 at
-            // 16, 46.7 at 32; 392 832 anchors 65.5 us at 8-16 rows, 74 at 32, 78 at 4)
+            // grid holds thousands of workgroups; with the tail-first dispatch order, 64 GT (profiles/r03y_ab_pairwise_rows.log):
+            // 98 208 anchors 18.5 us at 8 rows, 19.9 at 12, 20.2 at 16, 33.9 at 32; 392 832 anchors 49.1 us at 8, 47.0 at
+            // 12, 42.6 at 16, 41.1 at 22, 42.0 at 32 => about 4 096 workgroups, at least 8 rows, chunks of equal size
             const int64_t col_tiles = (n + kBlock - 1) / kBlock;
-            int64_t rpw = g_pw_rows > 0 ? g_pw_rows : (m * col_tiles) / 8192;
+            int64_t rpw = g_pw_rows > 0 ? g_pw_rows : (m * col_tiles) / 4096;
             if (rpw < 8 && g_pw_rows <= 0) rpw = 8;
             if (rpw < 4) rpw = 4;
             if (rpw > kPwRows) rpw = kPwRows;
             if (rpw > m) rpw = m;
+            if (g_pw_rows <= 0) rpw = (m + (m + rpw - 1) / rpw - 1) / ((m + rpw - 1) / rpw);   // 64 rows: 23 -> 3 chunks of 22 / 22 / 20
             dim3 grid((unsigned)col_tiles, (unsigned)((m + rpw - 1) / rpw));
             if (edge == SPH2POB_EDGE_ARC)
                 hipLaunchKernelGGL((iou_pairwise_compact_kernel<V >= 2 ? 0 : V, D, true>), grid, dim3(kBlock), 0, s, b1, (int)m, b2, (int)n,

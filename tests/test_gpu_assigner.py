@@ -31,7 +31,7 @@ def check(A, oracle, ov, labels=None, **kw):
     return res
 
 
-@pytest.mark.parametrize('k,n', [(1, 1), (3, 70), (64, 1000), (17, 4099), (200, 333)])
+@pytest.mark.parametrize('k,n', [(1, 1), (3, 70), (64, 1000), (17, 4099), (200, 333), (32, 257), (33, 65), (65, 31)])
 def test_random_matrices_bit_exact(A, oracle, k, n):
     rng = np.random.default_rng(k * 1000 + n)
     ov = rng.random((k, n)).astype(np.float32)
