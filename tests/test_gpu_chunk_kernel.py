@@ -111,6 +111,25 @@ def test_pairwise_tiles_with_merged_leftovers_match_aligned_bit_for_bit(dim, edg
             assert torch.equal(pw.reshape(-1), al)
 
 
+def test_pairwise_more_than_65535_column_tiles():
+    """the assigner kernel walks its column tiles from the last one backwards (a division of the linear workgroup id):
+    more than 65 535 tiles, 2 rows x 16 777 300 columns, against the aligned kernel"""
+    import torch
+    import sph_retina_amd as S
+    from bench import make_boxes
+    n = 65535 * 256 + 340
+    dev = torch.device('cuda', 0)
+    cols = make_boxes(n, 5, dev)
+    rows = make_boxes(2, 6, dev)
+    pw = S.sph2pob_standard_iou(rows, cols)
+    assert pw.shape == (2, n)
+    for r in range(2):
+        al = S.sph2pob_standard_iou(rows[r:r + 1].expand(n, 4).contiguous(), cols, is_aligned=True)
+        assert torch.equal(pw[r], al), r
+        del al
+    assert float((pw > 0).float().mean()) > 0.1
+
+
 def test_independent_calls_on_two_streams_give_the_same_bits():
     """calls that do not depend on each other may be issued on several HIP streams (their ramp-up and
     tail overlap); the launchers keep no state between calls, so the results are those of one stream"""
