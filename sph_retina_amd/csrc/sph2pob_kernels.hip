@@ -855,20 +855,25 @@ __global__ __launch_bounds__(kBlock) void nms_mask_compact_kernel(const float* _
 }
 
 // Greedy sweep, one WORKGROUP per class segment (classes are independent).  Every workgroup looks at 4 candidate rows;
-// a row that starts a class segment makes the whole workgroup sweep that segment's 64-row blocks in order:
-//   wave 0 resolves the serial dependency inside the block on the 64x64 diagonal block held one row per lane
-//   (v_readlane + scalar bit operations only) and publishes the kept rows of the block;
-//   all 256 threads then OR the kept rows' later words into the segment's "removed" bit-vector (LDS): a task is
-//   (word, group of 16 rows) — 16 independent loads in flight per thread — combined with an LDS atomic OR.
-// (With one wave per segment a thread owned a word and walked its 64 rows in 4 dependent batches: 2.4 us per block.)
-__global__ __launch_bounds__(kBlock) void nms_sweep_kernel(const unsigned long long* __restrict__ mask,
-                                                           const int64_t* __restrict__ cls, int64_t k, int words,
-                                                           unsigned char* __restrict__ keep) {
+// a row that starts a class segment makes the whole workgroup sweep that segment's 64-row blocks in order, as a two-stage
+// pipeline with one barrier per block:
+//   wave 0 resolves the serial dependency inside block b on the 64x64 diagonal block held one row per lane (v_readlane
+//   + scalar bit operations only), publishes the kept rows, and takes the kept rows' word b + 1 — the only word the NEXT
+//   resolve needs from this block — from a register it loaded one block ahead, with the diagonal;
+//   the other seven waves meanwhile OR the kept rows of block b - 1 into the words from b + 1 on of the segment's
+//   "removed" bit-vector (LDS): a task is (word, group of 16 rows) — 16 independent loads in flight per thread —
+//   combined with an LDS atomic OR.  Word b of the bit-vector is complete when block b is resolved: blocks up to b - 2
+//   reached it through the OR stage (a barrier ago at least), block b - 1 through wave 0's register.
+// (All threads ORing after every resolve, two barriers per block: 1.85 us per block; one wave per segment: 2.4 us.)
+constexpr int kSweepBlock = 512, kSweepCands = 4;
+__global__ __launch_bounds__(kSweepBlock) void nms_sweep_kernel(const unsigned long long* __restrict__ mask,
+                                                                const int64_t* __restrict__ cls, int64_t k, int words,
+                                                                unsigned char* __restrict__ keep) {
     __shared__ unsigned long long removed[kNmsMaxWords];
-    __shared__ unsigned long long kept_sh;
+    __shared__ unsigned long long kept_sh[2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int cand = 0; cand < kBlock / 64; cand++) {   // workgroup-uniform loop and conditions: barriers are safe
-        const int64_t s = (int64_t)blockIdx.x * (kBlock / 64) + cand;  // candidate segment head
+    for (int cand = 0; cand < kSweepCands; cand++) {   // workgroup-uniform loop and conditions: barriers are safe
+        const int64_t s = (int64_t)blockIdx.x * kSweepCands + cand;  // candidate segment head
         if (s >= k) break;
         if (cls ? (s > 0 && cls[s] == cls[s - 1]) : (s > 0)) continue;
         int64_t seg_end = k;
@@ -887,55 +892,62 @@ __global__ __launch_bounds__(kBlock) void nms_sweep_kernel(const unsigned long l
         const int limit = (words < kNmsMaxWords ? words : kNmsMaxWords) - 1;
         if (b_last > limit) b_last = limit;   // over-long segment: rows beyond the limit keep 0 flags
         __syncthreads();                      // the previous candidate's sweep is done with the shared state
-        for (int w = threadIdx.x; w <= b_last; w += kBlock) removed[w] = 0ull;
-        for (int64_t r = (base + b_last + 1) * 64 + threadIdx.x; r < seg_end; r += kBlock) keep[r] = 0;
+        for (int w = threadIdx.x; w <= b_last; w += kSweepBlock) removed[w] = 0ull;
+        for (int64_t r = (base + b_last + 1) * 64 + threadIdx.x; r < seg_end; r += kSweepBlock) keep[r] = 0;
         __syncthreads();
-        // the diagonal word of a block's rows depends on nothing the sweep computes: the next block's is requested
-        // while this block is resolved (the load's latency was on every block's critical path)
-        auto load_diag = [&](int b) -> unsigned long long {
+        // the diagonal word of a block's rows and the word after it depend on nothing the sweep computes: the next
+        // block's are requested while this block is resolved (the loads' latency was on every block's critical path)
+        auto load_word = [&](int b, int w) -> unsigned long long {
             const int64_t row = (base + b) * 64 + lane;
-            return (wave == 0 && b <= b_last && row >= s && row < seg_end) ? mask[row * words + b] : 0ull;
+            return (wave == 0 && b <= b_last && w <= b_last && row >= s && row < seg_end) ? mask[row * words + w] : 0ull;
         };
-        unsigned long long diag_next = load_diag(0);
+        unsigned long long diag_next = load_word(0, 0), after_next = load_word(0, 1);
+        unsigned long long carry = 0ull;   // wave 0, uniform: what block b - 1's kept rows remove in word b
         for (int b = 0; b <= b_last; b++) {
-            const int64_t row0 = (base + b) * 64;
             if (wave == 0) {
-                const int64_t row = row0 + lane;
+                const int64_t row = (base + b) * 64 + lane;
                 const bool mine = row >= s && row < seg_end;
-                const unsigned long long diag = diag_next;
-                diag_next = load_diag(b + 1);
+                const unsigned long long diag = diag_next, after = after_next;
+                diag_next = load_word(b + 1, b + 1);
+                after_next = load_word(b + 1, b + 2);
                 const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+                const unsigned alo = (unsigned)after, ahi = (unsigned)(after >> 32);
                 // scalar (SGPR) state of the serial chain; rows of the block outside this segment start out "removed"
                 // (the readlane builtins return int: cast before widening, or bit 31 sign-extends)
-                unsigned long long rem = removed[b] | ~__builtin_amdgcn_ballot_w64(mine);
+                unsigned long long rem = removed[b] | carry | ~__builtin_amdgcn_ballot_w64(mine);
                 rem = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(rem >> 32)) << 32) |
                       (unsigned)__builtin_amdgcn_readfirstlane((unsigned)rem);
                 // one step per KEPT row (s_ff1 on the rows still alive), not per row: a dense scene keeps a few of 64
                 unsigned long long keepbits = 0ull;
+                carry = 0ull;
                 while (~rem != 0ull) {
                     const int r = __builtin_ctzll(~rem);
                     keepbits |= 1ull << r;
                     rem |= (1ull << r) | ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, r) << 32) |
                            (unsigned)__builtin_amdgcn_readlane(dlo, r);
+                    carry |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ahi, r) << 32) |
+                             (unsigned)__builtin_amdgcn_readlane(alo, r);
                 }
                 if (mine) keep[row] = (unsigned char)((keepbits >> lane) & 1ull);
-                if (lane == 0) kept_sh = keepbits;
-            }
-            __syncthreads();
-            const unsigned long long keepbits = kept_sh;
-            const int ntasks = (b_last - b) * 4;   // (later word, group of 16 rows)
-            for (int t = threadIdx.x; t < ntasks; t += kBlock) {
-                const int w = b + 1 + (t >> 2), r0 = (t & 3) * 16;
-                const unsigned bits = (unsigned)(keepbits >> r0) & 0xffffu;
-                if (bits == 0u) continue;
-                const unsigned long long* col = mask + (row0 + r0) * words + w;
-                unsigned long long v[16];
+                if (lane == 0) kept_sh[b & 1] = keepbits;
+            } else if (b >= 1) {
+                // OR stage for block b - 1 (its kept rows were published before the last barrier): words b + 1 ... b_last
+                const unsigned long long keepbits = kept_sh[(b - 1) & 1];
+                const int64_t row0 = (base + b - 1) * 64;
+                const int ntasks = (b_last - b) * 4;   // (word, group of 16 rows)
+                for (int t = threadIdx.x - 64; t < ntasks; t += kSweepBlock - 64) {
+                    const int w = b + 1 + (t >> 2), r0 = (t & 3) * 16;
+                    const unsigned bits = (unsigned)(keepbits >> r0) & 0xffffu;
+                    if (bits == 0u) continue;
+                    const unsigned long long* col = mask + (row0 + r0) * words + w;
+                    unsigned long long v[16];
 #pragma unroll
-                for (int u = 0; u < 16; u++) v[u] = ((bits >> u) & 1u) ? col[(int64_t)u * words] : 0ull;
-                unsigned long long acc = 0ull;
+                    for (int u = 0; u < 16; u++) v[u] = ((bits >> u) & 1u) ? col[(int64_t)u * words] : 0ull;
+                    unsigned long long acc = 0ull;
 #pragma unroll
-                for (int u = 0; u < 16; u++) acc |= v[u];
-                if (acc) atomicOr(&removed[w], acc);
+                    for (int u = 0; u < 16; u++) acc |= v[u];
+                    if (acc) atomicOr(&removed[w], acc);
+                }
             }
             __syncthreads();
         }
@@ -1527,7 +1539,8 @@ int sph2pob_nms_segmented_f32(const float* boxes_sorted, const int64_t* cls_sort
 #undef SPH_NMS_COMPACT
     int rc = launch_status();
     if (rc) return rc;
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3((unsigned)((k + wpb - 1) / wpb)), dim3(kBlock), 0, s, mask, cls_sorted, k, words, keep);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3((unsigned)((k + kSweepCands - 1) / kSweepCands)), dim3(kSweepBlock), 0, s, mask, cls_sorted, k,
+                       words, keep);
     return launch_status();
 }
 
