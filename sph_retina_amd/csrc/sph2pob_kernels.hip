@@ -589,7 +589,9 @@ __global__ __launch_bounds__(kBlock) void loss_fwd_sum_kernel(const float* __res
     if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
-template <int DIM, bool FAST>
+// GT: the caller wants the target's gradient too.  A training step does not (the target carries no gradient): with GT =
+// false the target half of the chain rule back to the spherical inputs is dead code and the compiler drops it.
+template <int DIM, bool FAST, bool GT>
 __global__ __launch_bounds__(kBlock, FAST ? kLossWaves : 4) void loss_bwd_kernel(const float* __restrict__ pred,
                                                          const float* __restrict__ target,
                                                          const float* __restrict__ weight, int wd,
@@ -611,11 +613,11 @@ __global__ __launch_bounds__(kBlock, FAST ? kLossWaves : 4) void loss_bwd_kernel
     }
     if (DIM == 4) {
         reinterpret_cast<float4*>(gpred)[i] = make_float4(g * gx[0], g * gx[1], g * gx[2], g * gx[3]);
-        if (gtarget) reinterpret_cast<float4*>(gtarget)[i] = make_float4(g * gy[0], g * gy[1], g * gy[2], g * gy[3]);
+        if (GT) reinterpret_cast<float4*>(gtarget)[i] = make_float4(g * gy[0], g * gy[1], g * gy[2], g * gy[3]);
     } else {
 #pragma unroll
         for (int k = 0; k < 5; k++) gpred[i * 5 + k] = g * gx[k];
-        if (gtarget) {
+        if (GT) {
 #pragma unroll
             for (int k = 0; k < 5; k++) gtarget[i * 5 + k] = g * gy[k];
         }
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(kBlock, FAST ? kLossWaves : 4) void loss_bwd_kernel
 }
 
 // forward + gradients for an upstream gradient of 1 (+ per-workgroup partial sum of the loss when `partial`)
-template <int DIM, bool FAST>
+template <int DIM, bool FAST, bool GT>
 __global__ __launch_bounds__(kBlock, FAST ? kLossWaves : 4) void loss_fwd_grad_kernel(const float* __restrict__ pred,
                                                               const float* __restrict__ target,
                                                               const float* __restrict__ weight, int wd, float scale,
@@ -647,11 +649,11 @@ __global__ __launch_bounds__(kBlock, FAST ? kLossWaves : 4) void loss_fwd_grad_k
         if (loss) loss[i] = l;
         if (DIM == 4) {
             reinterpret_cast<float4*>(gpred)[i] = make_float4(w * gx[0], w * gx[1], w * gx[2], w * gx[3]);
-            if (gtarget) reinterpret_cast<float4*>(gtarget)[i] = make_float4(w * gy[0], w * gy[1], w * gy[2], w * gy[3]);
+            if (GT) reinterpret_cast<float4*>(gtarget)[i] = make_float4(w * gy[0], w * gy[1], w * gy[2], w * gy[3]);
         } else {
 #pragma unroll
             for (int k = 0; k < 5; k++) gpred[i * 5 + k] = w * gx[k];
-            if (gtarget) {
+            if (GT) {
 #pragma unroll
                 for (int k = 0; k < 5; k++) gtarget[i * 5 + k] = w * gy[k];
             }
@@ -1381,7 +1383,8 @@ int sph2pob_loss_bwd_f32(const float* pred, const float* target, const float* we
     dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
     hipStream_t s = (hipStream_t)stream;
 #define SPH_LOSS_BWD(D, F) \
-    hipLaunchKernelGGL((loss_bwd_kernel<D, F>), grid, dim3(kBlock), 0, s, pred, target, weight, weight_dim, grad_out, grad_stride, scale, grad_pred, grad_target, n, loss_mode, eps)
+    do { if (grad_target) hipLaunchKernelGGL((loss_bwd_kernel<D, F, true>), grid, dim3(kBlock), 0, s, pred, target, weight, weight_dim, grad_out, grad_stride, scale, grad_pred, grad_target, n, loss_mode, eps); \
+         else hipLaunchKernelGGL((loss_bwd_kernel<D, F, false>), grid, dim3(kBlock), 0, s, pred, target, weight, weight_dim, grad_out, grad_stride, scale, grad_pred, grad_target, n, loss_mode, eps); } while (0)
     if (box_dim == 4) { if (fast) SPH_LOSS_BWD(4, true); else SPH_LOSS_BWD(4, false); }
     else { if (fast) SPH_LOSS_BWD(5, true); else SPH_LOSS_BWD(5, false); }
 #undef SPH_LOSS_BWD
@@ -1438,7 +1441,8 @@ int sph2pob_loss_fwd_grad_f32(const float* pred, const float* target, const floa
     if (nb > 0) {
         dim3 grid((unsigned)nb);
 #define SPH_LOSS_FG(D, F) \
-        hipLaunchKernelGGL((loss_fwd_grad_kernel<D, F>), grid, dim3(kBlock), 0, s, pred, target, weight, weight_dim, scale, loss, partial, grad_pred, grad_target, n, loss_mode, eps)
+        do { if (grad_target) hipLaunchKernelGGL((loss_fwd_grad_kernel<D, F, true>), grid, dim3(kBlock), 0, s, pred, target, weight, weight_dim, scale, loss, partial, grad_pred, grad_target, n, loss_mode, eps); \
+             else hipLaunchKernelGGL((loss_fwd_grad_kernel<D, F, false>), grid, dim3(kBlock), 0, s, pred, target, weight, weight_dim, scale, loss, partial, grad_pred, grad_target, n, loss_mode, eps); } while (0)
         if (box_dim == 4) { if (fast) SPH_LOSS_FG(4, true); else SPH_LOSS_FG(4, false); }
         else { if (fast) SPH_LOSS_FG(5, true); else SPH_LOSS_FG(5, false); }
 #undef SPH_LOSS_FG
