@@ -343,6 +343,73 @@ def l1_only():
     save('l1', **arrs)
 
 
+ASSIGN_CFGS = (dict(pos_iou_thr=0.8, neg_iou_thr=0.75, min_pos_iou=0.0),
+               dict(pos_iou_thr=0.9, neg_iou_thr=(0.1, 0.8), min_pos_iou=0.75, gt_max_assign_all=False),
+               dict(pos_iou_thr=0.8, neg_iou_thr=0.8, match_low_quality=False),
+               dict(pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0.3),
+               dict(pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0.0, gt_max_assign_all=False))
+
+
+def assign_only():
+    """MaxIoUAssigner fixtures from the reference's real class (mmdet/core/bbox/assigners/max_iou_assigner.py:67-220):
+    (a) `assign_wrt_overlaps` on synthetic (k, n) matrices — exact zeros, ties on row and column maxima, ignored (-1)
+    columns, an all-zero GT row, an all-ignored matrix — under five threshold / flag configurations (float and tuple
+    `neg_iou_thr`, `gt_max_assign_all` and `match_low_quality` both ways); (b) `assign` on spherical boxes with the
+    reference's own `sph2pob_standard_iou` as the calculator, with and without `gt_bboxes_ignore` (both
+    `ignore_wrt_candidates` settings)."""
+    torch.manual_seed(20231101)
+    M = R.assigner.MaxIoUAssigner
+    arrs = {'n_cfg': len(ASSIGN_CFGS)}
+    shapes = [(1, 1), (3, 70), (64, 1000), (17, 4099), (33, 65), (65, 31), (5, 300)]
+    arrs['shapes'] = np.asarray(shapes)
+    for si, (k, n) in enumerate(shapes):
+        ov = torch.rand(k, n)
+        ov[ov < 0.7] = 0.0
+        ov[:, torch.randint(0, n, (max(1, n // 10),))] = -1.0
+        if n > 5:
+            ov[0, 3] = ov[0, 5] = ov[0].max()                     # tie on a row maximum
+        if k > 2:
+            ov[1, :] = torch.where(ov[1] < 0, ov[1], torch.zeros(()))   # a GT that overlaps nothing (all 0 / ignored)
+            ov[2, n // 2] = ov[0, n // 2] = 0.95                  # tie on a column maximum: first row wins
+        if si == 6:
+            ov[:] = -1.0                                          # every column ignored
+        labels = torch.randint(0, 37, (k,))
+        arrs[f's{si}_ov'], arrs[f's{si}_labels'] = ov, labels
+        for ci, cfg in enumerate(ASSIGN_CFGS):
+            a = M(iou_calculator=None, **cfg)
+            r = a.assign_wrt_overlaps(ov.clone(), labels)
+            r0 = a.assign_wrt_overlaps(ov.clone(), None)              # without labels: same indices, labels None
+            assert r0.labels is None and torch.equal(r0.gt_inds, r.gt_inds) and torch.equal(r0.max_overlaps, r.max_overlaps)
+            arrs[f's{si}_c{ci}_gt_inds'] = r.gt_inds.to(torch.int16)   # (stored narrow: the files stay small)
+            arrs[f's{si}_c{ci}_labels'] = r.labels.to(torch.int8)
+            if ci == 0:
+                arrs[f's{si}_max_overlaps'] = r.max_overlaps           # the same for every configuration
+            else:
+                assert torch.equal(arrs[f's{si}_max_overlaps'], r.max_overlaps)
+    # (b) spherical boxes: anchors scattered around the GTs + far ones
+    k, n = 12, 3000
+    gt = R.gen.generate_boxes(k, (0, 360), (20, 160), (5, 90), (5, 90), (-90, 90), dtype='float', box='bfov')
+    near = gt[torch.randint(0, k, (n // 2,))] + torch.randn(n // 2, 4) * torch.tensor([6., 6., 8., 8.])
+    near[:, 0] %= 360
+    near[:, 1] = near[:, 1].clamp(1, 179)
+    near[:, 2:] = near[:, 2:].clamp(1, 170)
+    far = R.gen.generate_boxes(n - n // 2, (0, 360), (0, 180), (1, 100), (1, 100), (-90, 90), dtype='float', box='bfov')
+    anchors = torch.cat([near, far])[torch.randperm(n)]
+    anchors[7] = gt[3]                                            # an exact copy of a GT
+    ignore = R.gen.generate_boxes(4, (0, 360), (30, 150), (30, 90), (30, 90), (-90, 90), dtype='float', box='bfov')
+    labels = torch.randint(0, 37, (k,))
+    calc = lambda a, b, mode='iou': R.api.sph2pob_standard_iou(a, b, mode=mode)   # noqa: E731
+    arrs.update(b_gt=gt, b_anchors=anchors, b_ignore=ignore, b_labels=labels, b_overlaps=calc(gt, anchors))
+    for ci, cfg in enumerate(ASSIGN_CFGS):
+        for tag, kw, ign in (('plain', {}, None), ('ignc', dict(ignore_iof_thr=0.5), ignore),
+                             ('ignb', dict(ignore_iof_thr=0.5, ignore_wrt_candidates=False), ignore)):
+            r = M(iou_calculator=calc, **cfg, **kw).assign(anchors, gt, gt_bboxes_ignore=ign, gt_labels=labels)
+            arrs[f'b_c{ci}_{tag}_gt_inds'], arrs[f'b_c{ci}_{tag}_labels'] = r.gt_inds.to(torch.int16), r.labels.to(torch.int8)
+            if ci == 0:
+                arrs[f'b_{tag}_max_overlaps'] = r.max_overlaps
+    save('assign', **arrs)
+
+
 def transform_bwd_only():
     """Gradients of the transforms that have no closed-form backward in the kernels — sph2pob_legacy and
     rbb_angle='project' of sph2pob_standard / sph2pob_efficient — from the reference's own torch autograd
@@ -414,6 +481,8 @@ if __name__ == '__main__':
         approx_only()
     elif len(sys.argv) > 1 and sys.argv[1] == 'coder':
         coder_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'assign':
+        assign_only()
     else:
         main()
         approx_only()
@@ -422,3 +491,4 @@ if __name__ == '__main__':
         l1_only()
         samples_backends_only()
         transform_bwd_only()
+        assign_only()

@@ -290,6 +290,20 @@ def assign_wrt_overlaps(overlaps, gt_labels=None, pos_iou_thr=0.5, neg_iou_thr=0
     return gt_inds, max_ov, argmax_ov.astype(np.int64), gt_max, gt_argmax.astype(np.int64), labels
 
 
+def assign(bboxes, gt_bboxes, iou_fn, gt_bboxes_ignore=None, gt_labels=None, ignore_iof_thr=-1, ignore_wrt_candidates=True,
+           **kw):
+    """MaxIoUAssigner.assign: mmdet/core/bbox/assigners/max_iou_assigner.py:113-127 (numpy) around a caller-supplied
+    `iou_fn(b1, b2, mode)` -> (len(b1), len(b2)); returns (overlaps after the ignore step, assign_wrt_overlaps(...))."""
+    ov = np.array(iou_fn(gt_bboxes, bboxes, 'iou'), dtype=np.float32)
+    if ignore_iof_thr > 0 and gt_bboxes_ignore is not None and len(gt_bboxes_ignore) and len(bboxes):
+        if ignore_wrt_candidates:
+            ig = np.asarray(iou_fn(bboxes, gt_bboxes_ignore, 'iof')).max(1)
+        else:
+            ig = np.asarray(iou_fn(gt_bboxes_ignore, bboxes, 'iof')).max(0)
+        ov[:, ig > np.float32(ignore_iof_thr)] = -1
+    return ov, assign_wrt_overlaps(ov, gt_labels, **kw)
+
+
 def generate_boxes(n, seed, box='bfov', alpha=(1, 100), beta=(1, 100), gamma=(-90, 90), theta=(0, 360),
                    phi=(0, 180)):
     """Synthetic boxes of the shape of tests/utils/generate_data.py:31-42 (dtype='float'), numpy RNG."""

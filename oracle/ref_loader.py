@@ -2,8 +2,7 @@
 
 Loads the torch-only modules of the reference from /root/reference by file path so that
 ``oracle/gen_goldens.py`` can emit the committed fixtures under ``tests/golden/`` and so that
-``tests/test_oracle_vs_reference.py`` can cross-check the C restatement while /root/reference is
-mounted.  Nothing here runs on the GPU box (the reference does not travel); every entry point
+``tests/test_oracle_golden.py`` can check the C / numpy restatements against them.  Nothing here runs on the GPU box (the reference does not travel); every entry point
 refuses to run when /root/reference is missing.
 
 Recipe: the reference's ``sphdet/iou/sph_iou_api.py:2`` imports the un-vendored
@@ -140,8 +139,21 @@ def load_reference():
     coder4 = _load('sphdet.bbox.coder.delta_xywh_sph_bbox_coder', 'sphdet/bbox/coder/delta_xywh_sph_bbox_coder.py')
     coder5 = _load('sphdet.bbox.coder.delta_xywha_rsph_bbox_coder', 'sphdet/bbox/coder/delta_xywha_rsph_bbox_coder.py')
 
+    # MaxIoUAssigner: the vendored mmdet class, unmodified (pure torch); registry + calculator builder stubbed — the
+    # calculator handed to the constructor is returned as it is (gen_goldens passes the reference's own IoU function)
+    cb.BBOX_ASSIGNERS = _Reg()
+    sys.modules.setdefault('mmdet.utils', types.ModuleType('mmdet.utils'))
+    sys.modules['mmdet.utils'].util_mixins = _load('mmdet.utils.util_mixins', 'mmdet/utils/util_mixins.py')
+    _pkg('mmdet.core.bbox.assigners', 'mmdet/core/bbox/assigners')
+    ic = types.ModuleType('mmdet.core.bbox.iou_calculators')
+    ic.build_iou_calculator = lambda cfg: cfg
+    sys.modules['mmdet.core.bbox.iou_calculators'] = ic
+    _load('mmdet.core.bbox.assigners.assign_result', 'mmdet/core/bbox/assigners/assign_result.py')
+    _load('mmdet.core.bbox.assigners.base_assigner', 'mmdet/core/bbox/assigners/base_assigner.py')
+    assigner = _load('mmdet.core.bbox.assigners.max_iou_assigner', 'mmdet/core/bbox/assigners/max_iou_assigner.py')
+
     ns = types.SimpleNamespace(
-        api=api, std=std, eff=eff, leg=leg, diff=diff, box_formator=box_formator, transform=tr, iou_loss=il,
+        assigner=assigner, api=api, std=std, eff=eff, leg=leg, diff=diff, box_formator=box_formator, transform=tr, iou_loss=il,
         nms=nms, gen=gen, loss_utils=lutils, coder4=coder4, coder5=coder5, l1_loss=l1)
     _CACHE['ns'] = ns
     return ns
