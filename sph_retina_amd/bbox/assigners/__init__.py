@@ -1,3 +1,3 @@
-from .max_iou_assigner import AssignResult, SphMaxIoUAssigner, assign_wrt_overlaps  # noqa: F401
+from .max_iou_assigner import AssignResult, SphMaxIoUAssigner, assign_wrt_overlaps, fused_assign  # noqa: F401
 
-__all__ = ['SphMaxIoUAssigner', 'AssignResult', 'assign_wrt_overlaps']
+__all__ = ['SphMaxIoUAssigner', 'AssignResult', 'assign_wrt_overlaps', 'fused_assign']

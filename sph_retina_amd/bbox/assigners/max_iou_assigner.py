@@ -6,6 +6,11 @@ constructor arguments, `assign(bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labe
 (`iou_calculator(gt_bboxes, bboxes)`, :113); everything after it — both `max` reductions, the threshold steps and the
 python `for i in range(num_gts)` low-quality loop, which costs one device->host sync per GT in the reference
 (:200-207) — is three kernel launches (`sph2pob_assign_f32`) with no host synchronisation.
+
+With a closed-form Sph2Pob calculator (`sph2pob_standard_iou` / `sph2pob_efficient_iou`, default arithmetic) `assign` goes
+one step further and never materialises the (k, n) overlaps (`sph2pob_iou_assign_f32`): the pairwise kernel keeps the
+per-anchor and per-GT maxima while it finishes the pairs, and the low-quality step re-evaluates a GT row only against the
+column tile that holds its maximum.  Bit-identical to the matrix route (tests/test_gpu_assigner.py).
 Not supported (raises): `gpu_assign_thr` CPU off-loading (there is no CPU path).
 """
 import ctypes
@@ -73,11 +78,7 @@ def assign_wrt_overlaps(overlaps, gt_labels=None, pos_iou_thr=0.5, neg_iou_thr=0
     G.require_hip(overlaps)
     ov = G.as_f32(overlaps.detach())
     dev = ov.device
-    if isinstance(neg_iou_thr, (tuple, list)):
-        assert len(neg_iou_thr) == 2
-        neg_lo, neg_hi = float(neg_iou_thr[0]), float(neg_iou_thr[1])
-    else:
-        neg_lo, neg_hi = 0.0, float(neg_iou_thr)
+    neg_lo, neg_hi = _thresholds(neg_iou_thr)
     max_ov = torch.empty((num_bboxes,), dtype=torch.float32, device=dev)
     argmax_ov = torch.empty((num_bboxes,), dtype=torch.int64, device=dev)
     gt_max = torch.empty((num_gts,), dtype=torch.float32, device=dev)
@@ -98,13 +99,66 @@ def assign_wrt_overlaps(overlaps, gt_labels=None, pos_iou_thr=0.5, neg_iou_thr=0
     return res
 
 
+def _thresholds(neg_iou_thr):
+    if isinstance(neg_iou_thr, (tuple, list)):
+        assert len(neg_iou_thr) == 2
+        return float(neg_iou_thr[0]), float(neg_iou_thr[1])
+    return 0.0, float(neg_iou_thr)
+
+
+_FUSED_BACKENDS = {'sph2pob_standard_iou': 'standard', 'sph2pob_efficient_iou': 'efficient'}
+
+
+def fused_assign(gt_bboxes, bboxes, gt_labels=None, variant='standard', pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0.0,
+                 gt_max_assign_all=True, match_low_quality=True, ignore_mask=None, rbb_edge='arc', return_overlaps=False,
+                 return_extras=False):
+    """`iou_calculator(gt_bboxes, bboxes)` + `assign_wrt_overlaps` (max_iou_assigner.py:113, :135-220) in three launches
+    without the (k, n) matrix (`return_overlaps=True` also writes it).  `ignore_mask`: optional (n,) bool, the columns the
+    reference sets to -1 (:115-126).  k > 0 and n > 0; boxes (k, 4|5) / (n, 4|5) on the MI355X."""
+    G.require_hip(gt_bboxes, bboxes)
+    gt, bx = G.as_f32_nograd(gt_bboxes), G.as_f32_nograd(bboxes)
+    k, n, dim = gt.size(0), bx.size(0), gt.size(1)
+    assert bx.size(1) == dim and dim in (4, 5) and k > 0 and n > 0
+    dev = bx.device
+    neg_lo, neg_hi = _thresholds(neg_iou_thr)
+    max_ov = torch.empty((n,), dtype=torch.float32, device=dev)
+    gt_inds = torch.empty((n,), dtype=torch.int64, device=dev)
+    keys = torch.empty((k,), dtype=torch.int64, device=dev)
+    labels = gl = argmax_ov = gt_max = gt_argmax = ov = ign = None
+    if gt_labels is not None:
+        gl = gt_labels.to(device=dev, dtype=torch.int64).contiguous()
+        labels = torch.empty((n,), dtype=torch.int64, device=dev)
+    if return_extras:
+        argmax_ov = torch.empty((n,), dtype=torch.int64, device=dev)
+        gt_max = torch.empty((k,), dtype=torch.float32, device=dev)
+        gt_argmax = torch.empty((k,), dtype=torch.int64, device=dev)
+    if return_overlaps:
+        ov = torch.empty((k, n), dtype=torch.float32, device=dev)
+    if ignore_mask is not None:
+        ign = ignore_mask.to(device=dev, dtype=torch.uint8).contiguous()
+    ws = torch.empty((_lib.lib().sph2pob_iou_assign_workspace_bytes(k, n) // 8,), dtype=torch.int64, device=dev)
+    G.call('sph2pob_iou_assign_f32', dev, G.ptr(gt), k, G.ptr(bx), n, dim, G.VARIANTS[variant], G.EDGES[rbb_edge], G.ptr(ign),
+           G.ptr(ov), pos_iou_thr, neg_lo, neg_hi, min_pos_iou, int(bool(match_low_quality)), int(bool(gt_max_assign_all)),
+           G.ptr(gl), G.ptr(max_ov), G.ptr(argmax_ov), G.ptr(gt_max), G.ptr(gt_argmax), G.ptr(gt_inds), G.ptr(labels),
+           G.ptr(keys), G.ptr(ws), G.raw_stream_of(dev))
+    res = AssignResult(k, gt_inds, max_ov if bboxes.dtype == torch.float32 or not bboxes.is_floating_point()
+                       else max_ov.to(bboxes.dtype), labels)
+    out = (res,)
+    if return_overlaps:
+        out += (ov,)
+    if return_extras:
+        out += (dict(argmax_overlaps=argmax_ov, gt_max_overlaps=gt_max, gt_argmax_overlaps=gt_argmax),)
+    return out[0] if len(out) == 1 else out
+
+
 @BBOX_ASSIGNERS.register_module(force=True)
 class SphMaxIoUAssigner:
     """Same constructor as mmdet's MaxIoUAssigner (:45-65); `iou_calculator` defaults to the Sph2Pob standard IoU."""
 
     def __init__(self, pos_iou_thr, neg_iou_thr, min_pos_iou=.0, gt_max_assign_all=True, ignore_iof_thr=-1,
                  ignore_wrt_candidates=True, match_low_quality=True, gpu_assign_thr=-1,
-                 iou_calculator=dict(type='SphOverlaps2D', backend='sph2pob_standard_iou', box_version=4)):
+                 iou_calculator=dict(type='SphOverlaps2D', backend='sph2pob_standard_iou', box_version=4), fused=True):
+        self.fused = fused   # False: always go through the (k, n) matrix (A/B and tests)
         self.pos_iou_thr = pos_iou_thr
         self.neg_iou_thr = neg_iou_thr
         self.min_pos_iou = min_pos_iou
@@ -118,15 +172,35 @@ class SphMaxIoUAssigner:
     def assign(self, bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None):
         if self.gpu_assign_thr > 0 and gt_bboxes.shape[0] > self.gpu_assign_thr:
             raise NotImplementedError('gpu_assign_thr (CPU off-loading) is not available: the engine has no CPU path')
-        overlaps = self.iou_calculator(gt_bboxes, bboxes)  # rows = GT (:113)
+        ignore_mask = None
         if (self.ignore_iof_thr > 0 and gt_bboxes_ignore is not None and gt_bboxes_ignore.numel() > 0
                 and bboxes.numel() > 0):  # :115-126
             if self.ignore_wrt_candidates:
                 ignore_max, _ = self.iou_calculator(bboxes, gt_bboxes_ignore, mode='iof').max(dim=1)
             else:
                 ignore_max, _ = self.iou_calculator(gt_bboxes_ignore, bboxes, mode='iof').max(dim=0)
-            overlaps[:, ignore_max > self.ignore_iof_thr] = -1
+            ignore_mask = ignore_max > self.ignore_iof_thr
+        variant = self._fused_variant(bboxes, gt_bboxes)
+        if variant is not None:   # no (k, n) matrix
+            v = self.iou_calculator.box_version
+            return fused_assign(gt_bboxes[..., :v], bboxes[..., :v], gt_labels, variant, self.pos_iou_thr, self.neg_iou_thr,
+                                self.min_pos_iou, self.gt_max_assign_all, self.match_low_quality, ignore_mask)
+        overlaps = self.iou_calculator(gt_bboxes, bboxes)  # rows = GT (:113)
+        if ignore_mask is not None:
+            overlaps[:, ignore_mask] = -1
         return self.assign_wrt_overlaps(overlaps, gt_labels)
+
+    def _fused_variant(self, bboxes, gt_bboxes):
+        """The closed-form variant the fused path serves, or None (another calculator / backend / arithmetic, empty inputs)."""
+        from ...iou.sph_iou_calculator import SphOverlaps2D
+        c = self.iou_calculator
+        if not self.fused or type(c) is not SphOverlaps2D or c.backend not in _FUSED_BACKENDS or G.get_arithmetic() == 'reference':
+            return None
+        if gt_bboxes.size(0) == 0 or bboxes.size(0) == 0 or c.box_version not in (4, 5) or not bboxes.is_cuda:
+            return None
+        if bboxes.size(-1) < c.box_version or gt_bboxes.size(-1) < c.box_version or gt_bboxes.size(0) > 262140:
+            return None
+        return _FUSED_BACKENDS[c.backend]
 
     def assign_wrt_overlaps(self, overlaps, gt_labels=None):
         return assign_wrt_overlaps(overlaps, gt_labels, self.pos_iou_thr, self.neg_iou_thr, self.min_pos_iou,

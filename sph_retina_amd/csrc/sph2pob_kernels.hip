@@ -377,6 +377,33 @@ __global__ __launch_bounds__(64 * WAVES, DIM == 4 ? 8 : 7) void iou_aligned_chun
 }
 
 // ---- pairwise IoU for the assigner call pattern (few rows x many columns), closed-form core ----
+// Order-preserving packed keys for max / first-argmax reductions (the assigner): (float bits mapped to an unsigned order) << 32
+// | ~index, so that the maximum key is the maximum value and, among equal values, the SMALLEST index — what torch.max(dim)
+// returns.  IoUs are >= +0 (the kernels never produce -0) or -1 for ignored columns.
+__device__ __forceinline__ unsigned long long pack_max_key(float v, int64_t j) {
+    // IoUs are >= 0 (or -1 for ignored columns): map to an order-preserving unsigned key; ties -> smallest index
+    unsigned u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned)(0xffffffffu - (unsigned)j);
+}
+__device__ __forceinline__ float unpack_max_val(unsigned long long key) {
+    unsigned u = (unsigned)(key >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long w = __shfl_xor(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+// keys travel between ranks as SIGNED 64-bit integers (torch.distributed has no unsigned MAX): top bit flipped
+__device__ __forceinline__ long long key_to_signed(unsigned long long k) { return (long long)(k ^ 0x8000000000000000ull); }
+__device__ __forceinline__ unsigned long long key_from_signed(long long k) { return (unsigned long long)k ^ 0x8000000000000000ull; }
+
 // One thread owns one column box (anchor); a workgroup covers 256 columns x up to 64 rows (GT).  Per-box cull
 // quantities are hoisted: rows live in LDS (broadcast reads), the column's in registers, so a culled pair costs
 // ~15 VALU instructions + one coalesced store of 0.  Survivors are (row, column) index pairs pushed on the wave's
@@ -386,11 +413,25 @@ constexpr int kPwRows = 64;
 // made this kernel 47 KB of code at 84 VGPRs).  The < 64 leftovers of the four waves are merged once at the end and
 // finished on as few, as full waves as possible (with 8 rows per workgroup a wave stacks ~80 survivors: one full pass and
 // a 16-lane one without the merge).
-template <int VARIANT, int DIM, bool ARC>
+// OUT: bit 0 = write the m x n matrix; bit 1 = the assigner's reductions (max_iou_assigner.py:171-176 without
+// the matrix) — every finished survivor with IoU > 0 goes into the tile's per-column and per-row maxima in LDS (ds_max_u64 on
+// packed keys; culled pairs and survivors that finish to 0 are covered by the initial values: exact zeros), written once per
+// workgroup as
+//   col_part[chunk][j]      max over the chunk's rows of (IoU[i][j], first row)         (chunk = blockIdx row chunk)
+//   row_part[i][tile]       max over the tile's 256 columns of (IoU[i][j], first column, global index = col_offset + j)
+// `ignore` (optional, one byte per column): columns whose overlaps the assigner sets to -1 (max_iou_assigner.py:115-126)
+// — they take part in no row maximum, their column maximum is (-1, row 0), and the matrix, when written, holds -1.
+constexpr int kRowSlots = 8;   // LDS copies of a row's running maximum (lane & 7): a pass holds a few rows, 64 lanes on one address serialise
+template <int VARIANT, int DIM, bool ARC, int OUT = 1>
 __global__ __launch_bounds__(kBlock, ARC ? 8 : 4) void iou_pairwise_compact_kernel(const float* __restrict__ b1, int m,
                                                                      const float* __restrict__ b2, int n,
                                                                      float* __restrict__ out, int mode, int edge_arg,
-                                                                     int rows_per_wg) {
+                                                                     int rows_per_wg,
+                                                                     const unsigned char* __restrict__ ignore = nullptr,
+                                                                     unsigned long long* __restrict__ col_part = nullptr,
+                                                                     unsigned long long* __restrict__ row_part = nullptr,
+                                                                     unsigned col_offset = 0) {
+    constexpr bool MATRIX = (OUT & 1) != 0, REDUCE = (OUT & 2) != 0;
     __shared__ float row_raw[kPwRows][5];
     __shared__ float4 row_cull[kPwRows];
     __shared__ int2 stack[kBlock / 64][kQCap];
@@ -400,6 +441,9 @@ __global__ __launch_bounds__(kBlock, ARC ? 8 : 4) void iou_pairwise_compact_kern
     // the survivors are compacted — reads them by index
     __shared__ ColatTrig row_trig[kPwRows];
     __shared__ ColatTrig col_trig[kBlock];
+    __shared__ unsigned long long col_key[REDUCE ? kBlock : 1];
+    __shared__ unsigned long long row_key[REDUCE ? kPwRows : 1][kRowSlots];
+    __shared__ unsigned long long tile_base;   // what a row holds before any survivor: (0, first live column) or (-1, first ignored one)
     const int edge = ARC ? (int)EDGE_ARC : edge_arg;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // dispatch order = LAST column tile first, all of its row chunks, then the tile before it: anchor grids end with their
@@ -427,8 +471,24 @@ __global__ __launch_bounds__(kBlock, ARC ? 8 : 4) void iou_pairwise_compact_kern
     const bool valid = j < n;
     float a[5] = {0.0f, 0.0f, 1.0f, 1.0f, 0.0f};
     if (valid) load_box<DIM>(b2, j, a);
+    const bool ign = (REDUCE || MATRIX) && ignore != nullptr && valid && ignore[j] != 0;
+    const bool live = valid & !ign;
     col_trig[threadIdx.x] = colat_trig(a[1], 2);
+    if constexpr (REDUCE) {
+        col_key[threadIdx.x] = pack_max_key(ign ? -1.0f : 0.0f, r0);
+        if (threadIdx.x < kPwRows * kRowSlots) (&row_key[0][0])[threadIdx.x] = 0ull;
+        if (kPwRows * kRowSlots > kBlock && threadIdx.x + kBlock < kPwRows * kRowSlots) (&row_key[0][0])[threadIdx.x + kBlock] = 0ull;
+        if (threadIdx.x == 0) tile_base = 0ull;
+    }
     __syncthreads();
+    if constexpr (REDUCE) {   // first live / first ignored column of each wave -> the tile's base key (a max over <= 8 candidates)
+        const unsigned long long ml = __builtin_amdgcn_ballot_w64(live), mi = __builtin_amdgcn_ballot_w64(ign);
+        if (lane == 0) {
+            const int jw = bx * kBlock + wave * 64;
+            if (ml) atomicMax(&tile_base, pack_max_key(0.0f, (int64_t)col_offset + jw + __builtin_ctzll(ml)));
+            if (mi) atomicMax(&tile_base, pack_max_key(-1.0f, (int64_t)col_offset + jw + __builtin_ctzll(mi)));
+        }
+    }
     const CullBox ca = cull_box(a, edge);
     int2* st = stack[wave];
     int count = 0;
@@ -437,15 +497,22 @@ __global__ __launch_bounds__(kBlock, ARC ? 8 : 4) void iou_pairwise_compact_kern
 #pragma unroll
         for (int k = 0; k < 5; k++) g[k] = row_raw[e.x][k];
         load_box<DIM>(b2, e.y, p);
-        out[(int64_t)(r0 + e.x) * n + e.y] = lean_finish<VARIANT, DIM, 1>(g, p, mode, edge, row_trig[e.x], col_trig[e.y - bx * kBlock]);
+        const float v = lean_finish<VARIANT, DIM, 1>(g, p, mode, edge, row_trig[e.x], col_trig[e.y - bx * kBlock]);
+        if constexpr (MATRIX) out[(int64_t)(r0 + e.x) * n + e.y] = v;
+        if constexpr (REDUCE) if (!(v <= 0.0f)) {   // > 0 or NaN: zeros are the initial values
+            atomicMax(&col_key[e.y - bx * kBlock], pack_max_key(v, r0 + e.x));
+            atomicMax(&row_key[e.x][lane & (kRowSlots - 1)], pack_max_key(v, (int64_t)col_offset + e.y));
+        }
     };
     float* orow = out + (int64_t)r0 * n + j;   // this column's element of the tile's first row (cull rows at a higher
                                                // wave priority than the passes, as in the chunk kernel: no gain here)
     for (int i = 0; i < rows; i++) {
         const float4 rc = row_cull[i];
-        const bool culled = cull_pair(CullBox{rc.x, rc.y, rc.z, rc.w}, ca), surv = valid & !culled;
-        if (valid & culled) *orow = 0.0f;
-        orow += n;
+        const bool culled = cull_pair(CullBox{rc.x, rc.y, rc.z, rc.w}, ca), surv = live & !culled;
+        if constexpr (MATRIX) {
+            if (valid & (culled | ign)) *orow = ign ? -1.0f : 0.0f;
+            orow += n;
+        }
         const unsigned long long mk = __builtin_amdgcn_ballot_w64(surv);
         if (surv) st[count + rank_below(mk)] = make_int2(i, j);
         count += __popcll(mk);
@@ -467,6 +534,16 @@ __global__ __launch_bounds__(kBlock, ARC ? 8 : 4) void iou_pairwise_compact_kern
             int w = 0;
             if (k >= c0) { k -= c0; w = 1; if (k >= c1) { k -= c1; w = 2; if (k >= c2) { k -= c2; w = 3; } } }
             finish_one(stack[w][k]);
+        }
+    }
+    if constexpr (REDUCE) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (valid) col_part[(int64_t)by * n + j] = col_key[threadIdx.x];
+        if ((int)threadIdx.x < rows) {
+            unsigned long long best = tile_base;
+#pragma unroll
+            for (int t = 0; t < kRowSlots; t++) { const unsigned long long v = row_key[threadIdx.x][t]; best = v > best ? v : best; }
+            row_part[(int64_t)(r0 + threadIdx.x) * gridDim.x + bx] = best;
         }
     }
 }
@@ -962,26 +1039,6 @@ __global__ __launch_bounds__(kSweepBlock) void nms_sweep_kernel(const unsigned l
 // ---- MaxIoUAssigner epilogue: replaces overlaps.max(dim=0), overlaps.max(dim=1), the threshold steps
 // and the python `for i in range(num_gts)` low-quality loop (one host sync per GT) of
 // mmdet/core/bbox/assigners/max_iou_assigner.py:171-207 with three launches over the (k, n) overlaps matrix. ----
-__device__ __forceinline__ unsigned long long pack_max_key(float v, int64_t j) {
-    // IoUs are >= 0 (or -1 for ignored columns): map to an order-preserving unsigned key; ties -> smallest index
-    unsigned u = __float_as_uint(v);
-    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    return ((unsigned long long)u << 32) | (unsigned)(0xffffffffu - (unsigned)j);
-}
-__device__ __forceinline__ float unpack_max_val(unsigned long long key) {
-    unsigned u = (unsigned)(key >> 32);
-    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-    return __uint_as_float(u);
-}
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        unsigned long long w = __shfl_xor(v, o, 64);
-        v = w > v ? w : v;
-    }
-    return v;
-}
-
 // A: one thread per column (anchor): running max / first argmax over the k rows, and per-wave row partials.
 // Rows are taken 32 at a time: 32 independent coalesced loads per lane (unconditional, on clamped addresses, into a
 // register array: written as `live ? ov[..] : -inf` each load sat behind its own branch and its own wait — 64 serial
@@ -1109,6 +1166,130 @@ __global__ __launch_bounds__(kBlock) void assign_finalize_kernel(const float* __
     if (labels) labels[j] = a > 0 ? gt_labels[a - 1] : -1;
 }
 
+// ---- fused assigner (no k x n matrix): phase 2 and 3 behind iou_pairwise_compact_kernel<.., OUT & 2> ----
+// B': one workgroup per row (GT): maximum of the row's per-tile partials -> one signed-order key per GT (what a job
+// sharded on the box axis all-reduces with MAX)
+__global__ __launch_bounds__(kBlock) void assign_row_keys_kernel(const unsigned long long* __restrict__ partial, int nparts,
+                                                                long long* __restrict__ gt_keys) {
+    __shared__ unsigned long long sm[kBlock / 64];
+    const int i = blockIdx.x;
+    unsigned long long best = 0ull;
+    for (int p0 = threadIdx.x; p0 < nparts; p0 += kBlock * 8) {
+        unsigned long long v[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const int p = p0 + t * kBlock;
+            v[t] = partial[(int64_t)i * nparts + (p < nparts ? p : nparts - 1)];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; t++) best = v[t] > best ? v[t] : best;
+    }
+    best = wave_max_u64(best);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; w++) best = sm[w] > best ? sm[w] : best;
+        gt_keys[i] = key_to_signed(best);
+    }
+}
+// C': one workgroup per column tile (the tiles of phase 1).  Column maxima from the row chunks' partials, thresholds, and
+// the low-quality step (max_iou_assigner.py:192-207) without the matrix: `overlaps[i, :] == gt_max[i]` can hold in this tile
+//   * for gt_max[i] == 0 on every column that is not ignored (nothing overlaps GT i: every live IoU of the row is 0);
+//   * for gt_max[i] == -1 on every ignored column (the whole row is ignored columns);
+//   * for gt_max[i] > 0 only if the TILE's maximum of row i (row_part, still in the workspace) equals it — then, and only
+//     then, the row is evaluated again against the tile's 256 columns with the very functions phase 1 ran (same inputs, same
+//     bits): a handful of (row, tile) pairs per call.
+// Later GTs overwrite earlier ones in the reference's loop: the largest matching i wins.
+template <int VARIANT, int DIM, bool ARC>
+__global__ __launch_bounds__(kBlock) void assign_fused_finalize_kernel(const float* __restrict__ b1, int k, const float* __restrict__ b2, int n,
+                                                                      int edge_arg, const unsigned long long* __restrict__ col_part, int chunks,
+                                                                      const unsigned long long* __restrict__ row_part,
+                                                                      const long long* __restrict__ gt_keys, unsigned col_offset,
+                                                                      float pos_thr, float neg_lo, float neg_hi, float min_pos,
+                                                                      int low_quality, int assign_all,
+                                                                      const int64_t* __restrict__ gt_labels,
+                                                                      float* __restrict__ max_ov, int64_t* __restrict__ argmax_ov,
+                                                                      float* __restrict__ gt_max, int64_t* __restrict__ gt_argmax,
+                                                                      int64_t* __restrict__ gt_inds, int64_t* __restrict__ labels) {
+    const int edge = ARC ? (int)EDGE_ARC : edge_arg;
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x, tiles = gridDim.x;
+    const int jraw = tile * kBlock + threadIdx.x;
+    const bool valid = jraw < n;
+    const int j = valid ? jraw : n - 1;
+    if (tile == 0 && gt_max) {   // the per-GT results, decoded once
+        for (int i = threadIdx.x; i < k; i += kBlock) {
+            const unsigned long long key = key_from_signed(gt_keys[i]);
+            gt_max[i] = unpack_max_val(key);
+            if (gt_argmax) gt_argmax[i] = (int64_t)(0xffffffffu - (unsigned)key);
+        }
+    }
+    unsigned long long ck = 0ull;
+    for (int c0 = 0; c0 < chunks; c0 += 8) {   // 8 independent loads per round (a repeated last chunk changes no maximum)
+        unsigned long long v[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) v[t] = col_part[(int64_t)(c0 + t < chunks ? c0 + t : chunks - 1) * n + j];
+#pragma unroll
+        for (int t = 0; t < 8; t++) ck = v[t] > ck ? v[t] : ck;
+    }
+    const float m = unpack_max_val(ck);
+    const int64_t am = (int64_t)(0xffffffffu - (unsigned)ck);
+    const bool ign = m < 0.0f;   // only an ignored column has a negative maximum
+    int64_t a = -1;
+    if (m >= neg_lo && m < neg_hi) a = 0;
+    if (m >= pos_thr) a = am + 1;
+    if (low_quality) {
+        int best = -1;
+        if (!assign_all) {
+            for (int i = 0; i < k; i++) {
+                const unsigned long long key = key_from_signed(gt_keys[i]);
+                if (unpack_max_val(key) >= min_pos && (0xffffffffu - (unsigned)key) == col_offset + (unsigned)j) best = i;
+            }
+        } else {
+            float a5[5] = {0.0f, 0.0f, 1.0f, 1.0f, 0.0f};
+            bool have_box = false;
+            CullBox ca{};
+            ColatTrig ct{};
+            for (int r0 = 0; r0 < k; r0 += 64) {
+                const int il = r0 + lane, ic = il < k ? il : k - 1;
+                const unsigned long long gk = key_from_signed(gt_keys[ic]);
+                const float g = unpack_max_val(gk);
+                const bool on = il < k && g >= min_pos;
+                const unsigned long long zero = __builtin_amdgcn_ballot_w64(on && g == 0.0f);
+                const unsigned long long neg = __builtin_amdgcn_ballot_w64(on && g == -1.0f);
+                const unsigned long long pk = row_part[(int64_t)ic * tiles + tile];
+                unsigned long long rec = __builtin_amdgcn_ballot_w64(on && g > 0.0f && (unsigned)(pk >> 32) == (unsigned)(gk >> 32));
+                if (!ign && zero) best = r0 + 63 - __builtin_clzll(zero);
+                if (ign && neg) { const int t = r0 + 63 - __builtin_clzll(neg); best = t > best ? t : best; }
+                while (rec) {   // wave-uniform: rows whose maximum lives in this tile
+                    const int t = __builtin_ctzll(rec);
+                    rec &= rec - 1;
+                    if (!have_box) {
+                        if (valid) load_box<DIM>(b2, j, a5);
+                        ca = cull_box(a5, edge);
+                        ct = colat_trig(a5[1], 2);
+                        have_box = true;
+                    }
+                    float g5[5];
+                    load_box<DIM>(b1, r0 + t, g5);
+                    const CullBox cg = cull_box(g5, edge);
+                    float v = 0.0f;
+                    if (!cull_pair(cg, ca)) v = lean_finish<VARIANT, DIM, 1>(g5, a5, MODE_IOU, edge, colat_trig(g5[1], 1), ct);
+                    const float gm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g), t));
+                    if (!ign && v == gm && r0 + t > best) best = r0 + t;
+                }
+            }
+        }
+        if (best >= 0) a = best + 1;
+    }
+    if (!valid) return;
+    max_ov[j] = m;
+    if (argmax_ov) argmax_ov[j] = am;
+    gt_inds[j] = a;
+    if (labels) labels[j] = a > 0 ? gt_labels[a - 1] : -1;
+}
+
 // ---- adjoint of the Sph2Pob transform: gradients of the planar boxes -> gradients of the spherical boxes ----
 template <int VARIANT, int DIM>
 __global__ __launch_bounds__(kBlock) void transform_bwd_kernel(const float* __restrict__ b1, const float* __restrict__ b2,
@@ -1217,29 +1398,37 @@ struct AlignedLaunch {
         return launch_status();
     }
 };
+// rows per workgroup of iou_pairwise_compact_kernel: enough to amortise the per-column setup and fill the survivor stacks,
+// few enough that the grid holds thousands of workgroups; with the tail-first dispatch order, 64 GT
+// (profiles/r03y_ab_pairwise_rows.log): 98 208 anchors 18.5 us at 8 rows, 19.9 at 12, 20.2 at 16, 33.9 at 32; 392 832
+// anchors 49.1 us at 8, 47.0 at 12, 42.6 at 16, 41.1 at 22, 42.0 at 32 => about 4 096 workgroups, at least 8 rows, chunks of
+// equal size
+static int64_t pairwise_rows_per_wg(int64_t m, int64_t n) {
+    const int64_t col_tiles = (n + kBlock - 1) / kBlock;
+    int64_t rpw = g_pw_rows > 0 ? g_pw_rows : (m * col_tiles) / 4096;
+    if (rpw < 8 && g_pw_rows <= 0) rpw = 8;
+    if (rpw < 4) rpw = 4;
+    if (rpw > kPwRows) rpw = kPwRows;
+    if (rpw > m) rpw = m;
+    if (g_pw_rows <= 0) rpw = (m + (m + rpw - 1) / rpw - 1) / ((m + rpw - 1) / rpw);   // 64 rows: 23 -> 3 chunks of 22 / 22 / 20
+    return rpw;
+}
 struct PairwiseLaunch {
     const float* b1; int64_t m; const float* b2; int64_t n; float* out; int mode, edge, angle; hipStream_t s; bool fast = true;
     template <int V, int D> int run() {
         if (fast && V < 2 && angle == SPH2POB_ANGLE_EQUATOR && n < ((int64_t)1 << 31) - kBlock && m <= (int64_t)65535 * 4 &&
             !g_no_compact) {
-            // rows per workgroup: enough to amortise the per-column setup and fill the survivor stacks, few enough that the
-            // grid holds thousands of workgroups; with the tail-first dispatch order, 64 GT (profiles/r03y_ab_pairwise_rows.log):
-            // 98 208 anchors 18.5 us at 8 rows, 19.9 at 12, 20.2 at 16, 33.9 at 32; 392 832 anchors 49.1 us at 8, 47.0 at
-            // 12, 42.6 at 16, 41.1 at 22, 42.0 at 32 => about 4 096 workgroups, at least 8 rows, chunks of equal size
             const int64_t col_tiles = (n + kBlock - 1) / kBlock;
-            int64_t rpw = g_pw_rows > 0 ? g_pw_rows : (m * col_tiles) / 4096;
-            if (rpw < 8 && g_pw_rows <= 0) rpw = 8;
-            if (rpw < 4) rpw = 4;
-            if (rpw > kPwRows) rpw = kPwRows;
-            if (rpw > m) rpw = m;
-            if (g_pw_rows <= 0) rpw = (m + (m + rpw - 1) / rpw - 1) / ((m + rpw - 1) / rpw);   // 64 rows: 23 -> 3 chunks of 22 / 22 / 20
+            const int64_t rpw = pairwise_rows_per_wg(m, n);
             dim3 grid((unsigned)col_tiles, (unsigned)((m + rpw - 1) / rpw));
             if (edge == SPH2POB_EDGE_ARC)
-                hipLaunchKernelGGL((iou_pairwise_compact_kernel<V >= 2 ? 0 : V, D, true>), grid, dim3(kBlock), 0, s, b1, (int)m, b2, (int)n,
-                                   out, mode, edge, (int)rpw);
+                hipLaunchKernelGGL((iou_pairwise_compact_kernel<V >= 2 ? 0 : V, D, true, 1>), grid, dim3(kBlock), 0, s, b1, (int)m, b2, (int)n,
+                                   out, mode, edge, (int)rpw, (const unsigned char*)nullptr, (unsigned long long*)nullptr,
+                                   (unsigned long long*)nullptr, 0u);
             else
-                hipLaunchKernelGGL((iou_pairwise_compact_kernel<V >= 2 ? 0 : V, D, false>), grid, dim3(kBlock), 0, s, b1, (int)m, b2, (int)n,
-                                   out, mode, edge, (int)rpw);
+                hipLaunchKernelGGL((iou_pairwise_compact_kernel<V >= 2 ? 0 : V, D, false, 1>), grid, dim3(kBlock), 0, s, b1, (int)m, b2, (int)n,
+                                   out, mode, edge, (int)rpw, (const unsigned char*)nullptr, (unsigned long long*)nullptr,
+                                   (unsigned long long*)nullptr, 0u);
             return launch_status();
         }
         // grid.y is limited to 65535 rows per launch: walk the rows in slabs
@@ -1260,6 +1449,55 @@ struct PairwiseLaunch {
             if (rc) return rc;
         }
         return SPH2POB_OK;
+    }
+};
+// the fused assigner's two halves (closed-form standard / efficient only: the kernels that carry the reductions)
+struct AssignWs { unsigned long long *col_part, *row_part; int64_t chunks, tiles; };
+static AssignWs assign_ws(void* workspace, int64_t k, int64_t n) {
+    AssignWs w;
+    w.tiles = (n + kBlock - 1) / kBlock;
+    const int64_t rpw = pairwise_rows_per_wg(k, n);
+    w.chunks = (k + rpw - 1) / rpw;
+    w.col_part = (unsigned long long*)workspace;
+    w.row_part = w.col_part + w.chunks * n;
+    return w;
+}
+struct AssignReduceLaunch {
+    const float* b1; int64_t m; const float* b2; int64_t n; float* out; int edge; const unsigned char* ignore; unsigned col_offset;
+    long long* gt_keys; void* workspace; hipStream_t s; bool fast = true;
+    template <int V, int D> int run() {
+        if constexpr (V >= 2) return SPH2POB_ERR_OPTION;
+        else {
+            if (!fast) return SPH2POB_ERR_OPTION;
+            const AssignWs w = assign_ws(workspace, m, n);
+            const int64_t rpw = pairwise_rows_per_wg(m, n);
+            dim3 grid((unsigned)w.tiles, (unsigned)w.chunks);
+#define SPH_AR(ARC, OUT) hipLaunchKernelGGL((iou_pairwise_compact_kernel<V, D, ARC, OUT>), grid, dim3(kBlock), 0, s, b1, (int)m, b2, (int)n, out, \
+                                           (int)MODE_IOU, edge, (int)rpw, ignore, w.col_part, w.row_part, col_offset)
+            if (edge == SPH2POB_EDGE_ARC) { if (out) SPH_AR(true, 3); else SPH_AR(true, 2); }
+            else { if (out) SPH_AR(false, 3); else SPH_AR(false, 2); }
+#undef SPH_AR
+            hipLaunchKernelGGL(assign_row_keys_kernel, dim3((unsigned)m), dim3(kBlock), 0, s, w.row_part, (int)w.tiles, gt_keys);
+            return launch_status();
+        }
+    }
+};
+struct AssignFinalizeLaunch {
+    const float* b1; int64_t m; const float* b2; int64_t n; int edge; unsigned col_offset; const long long* gt_keys;
+    float pos, neg_lo, neg_hi, min_pos; int low_quality, assign_all; const int64_t* gt_labels; float* max_ov; int64_t* argmax_ov;
+    float* gt_max; int64_t* gt_argmax; int64_t* gt_inds; int64_t* labels; void* workspace; hipStream_t s; bool fast = true;
+    template <int V, int D> int run() {
+        if constexpr (V >= 2) return SPH2POB_ERR_OPTION;
+        else {
+            if (!fast) return SPH2POB_ERR_OPTION;
+            const AssignWs w = assign_ws(workspace, m, n);
+#define SPH_AF(ARC) hipLaunchKernelGGL((assign_fused_finalize_kernel<V, D, ARC>), dim3((unsigned)w.tiles), dim3(kBlock), 0, s, b1, (int)m, b2, (int)n, \
+                                      edge, w.col_part, (int)w.chunks, w.row_part, gt_keys, col_offset, pos, neg_lo, neg_hi, min_pos, low_quality,  \
+                                      assign_all, gt_labels, max_ov, argmax_ov, gt_max, gt_argmax, gt_inds, labels)
+            if (edge == SPH2POB_EDGE_ARC) SPH_AF(true); else SPH_AF(false);
+#undef SPH_AF
+            return launch_status();
+        }
     }
 };
 struct TransformLaunch {
@@ -1584,6 +1822,62 @@ int sph2pob_assign_f32(const float* overlaps, int64_t k, int64_t n, float pos_io
                        argmax_overlaps, gt_max_overlaps, gt_argmax_overlaps, pos_iou_thr, neg_iou_lo, neg_iou_hi,
                        min_pos_iou, match_low_quality, gt_max_assign_all, gt_labels, assigned_gt_inds, assigned_labels);
     return launch_status();
+}
+
+int64_t sph2pob_iou_assign_workspace_bytes(int64_t k, int64_t n) {
+    if (k <= 0 || n <= 0) return 0;
+    const AssignWs w = assign_ws(nullptr, k, n);
+    return (w.chunks * n + k * w.tiles) * 8;
+}
+
+static int assign_fused_check(int64_t k, int64_t n, int box_dim, int variant, int edge, int64_t col_offset) {
+    int rc = check_common(box_dim, variant, edge, 0);
+    if (rc) return rc;
+    if ((variant & 0xff) > SPH2POB_VARIANT_EFFICIENT || (variant & SPH2POB_FLAG_REFERENCE_ORDER)) return SPH2POB_ERR_OPTION;
+    if (k <= 0 || n <= 0 || n >= ((int64_t)1 << 31) - kBlock || k > (int64_t)65535 * 4 || col_offset < 0 ||
+        col_offset + n > (int64_t)0xfffffffe)
+        return SPH2POB_ERR_SIZE;
+    return SPH2POB_OK;
+}
+
+int sph2pob_iou_assign_reduce_f32(const float* gt, int64_t k, const float* boxes, int64_t n, int box_dim, int variant, int edge,
+                                  const unsigned char* ignore, int64_t col_offset, float* overlaps, int64_t* gt_keys,
+                                  void* workspace, void* stream) {
+    int rc = assign_fused_check(k, n, box_dim, variant, edge, col_offset);
+    if (rc) return rc;
+    if (!gt || !boxes || !gt_keys || !workspace) return SPH2POB_ERR_NULL;
+    return dispatch(variant, box_dim, AssignReduceLaunch{gt, k, boxes, n, overlaps, edge, ignore, (unsigned)col_offset,
+                                                         (long long*)gt_keys, workspace, (hipStream_t)stream});
+}
+
+int sph2pob_iou_assign_finalize_f32(const float* gt, int64_t k, const float* boxes, int64_t n, int box_dim, int variant, int edge,
+                                    int64_t col_offset, const int64_t* gt_keys, float pos_iou_thr, float neg_iou_lo,
+                                    float neg_iou_hi, float min_pos_iou, int match_low_quality, int gt_max_assign_all,
+                                    const int64_t* gt_labels, float* max_overlaps, int64_t* argmax_overlaps,
+                                    float* gt_max_overlaps, int64_t* gt_argmax_overlaps, int64_t* assigned_gt_inds,
+                                    int64_t* assigned_labels, void* workspace, void* stream) {
+    int rc = assign_fused_check(k, n, box_dim, variant, edge, col_offset);
+    if (rc) return rc;
+    if (!gt || !boxes || !gt_keys || !workspace || !max_overlaps || !assigned_gt_inds || (assigned_labels && !gt_labels))
+        return SPH2POB_ERR_NULL;
+    return dispatch(variant, box_dim,
+                    AssignFinalizeLaunch{gt, k, boxes, n, edge, (unsigned)col_offset, (const long long*)gt_keys, pos_iou_thr,
+                                         neg_iou_lo, neg_iou_hi, min_pos_iou, match_low_quality, gt_max_assign_all, gt_labels,
+                                         max_overlaps, argmax_overlaps, gt_max_overlaps, gt_argmax_overlaps, assigned_gt_inds,
+                                         assigned_labels, workspace, (hipStream_t)stream});
+}
+
+int sph2pob_iou_assign_f32(const float* gt, int64_t k, const float* boxes, int64_t n, int box_dim, int variant, int edge,
+                           const unsigned char* ignore, float* overlaps, float pos_iou_thr, float neg_iou_lo, float neg_iou_hi,
+                           float min_pos_iou, int match_low_quality, int gt_max_assign_all, const int64_t* gt_labels,
+                           float* max_overlaps, int64_t* argmax_overlaps, float* gt_max_overlaps, int64_t* gt_argmax_overlaps,
+                           int64_t* assigned_gt_inds, int64_t* assigned_labels, int64_t* gt_keys, void* workspace, void* stream) {
+    int rc = sph2pob_iou_assign_reduce_f32(gt, k, boxes, n, box_dim, variant, edge, ignore, 0, overlaps, gt_keys, workspace, stream);
+    if (rc) return rc;
+    return sph2pob_iou_assign_finalize_f32(gt, k, boxes, n, box_dim, variant, edge, 0, gt_keys, pos_iou_thr, neg_iou_lo, neg_iou_hi,
+                                           min_pos_iou, match_low_quality, gt_max_assign_all, gt_labels, max_overlaps,
+                                           argmax_overlaps, gt_max_overlaps, gt_argmax_overlaps, assigned_gt_inds,
+                                           assigned_labels, workspace, stream);
 }
 
 int sph2pob_transform_bwd_f32(const float* b1, const float* b2, const float* grad_planar1, const float* grad_planar2,
