@@ -239,24 +239,32 @@ int sph2pob_assign_f32(const float* overlaps, int64_t k, int64_t n, float pos_io
  * sph2pob_efficient_iou calculators (variant STANDARD | EFFICIENT, default arithmetic, rbb_angle 'equator', mode 'iou'):
  * the pairwise kernel keeps per-column and per-row running maxima (first index on ties, like torch.max) while it
  * finishes the pairs — culled pairs are exact zeros — and the finalize pass applies the thresholds and the low-quality
- * step, re-evaluating a GT row only against the column tile that holds its maximum.  Results are bit-identical to
+ * step (a GT row is re-evaluated only against a column tile that holds its maximum more than once).  Results are bit-identical to
  * sph2pob_iou_pairwise_f32 followed by sph2pob_assign_f32.
  *   ignore       optional (n) bytes: non-zero = the column's overlaps are -1 (`overlaps[:, ignore_max > thr] = -1`, :115-126)
  *   overlaps     optional (k, n): also write the matrix (for callers that want it; the assignment does not read it)
- *   gt_keys      (k) int64 scratch / exchange: per-GT (max IoU, first global column) as keys that order as SIGNED integers
+ *   gt_keys      (k) int64, the exchange format of the sharded form: per-GT (max IoU, first global column) as keys that
+ *                order as SIGNED integers (torch.distributed / RCCL have no unsigned MAX)
  *   col_offset   global index of this shard's first column (0 when not sharded)
- *   workspace    sph2pob_iou_assign_workspace_bytes(k, n) bytes; must stay untouched between reduce and finalize
- * Two halves so that a job sharded on the box axis can put ONE all-reduce(MAX) of the k keys between them:
- * reduce = pairwise kernel + per-GT keys of this shard; finalize = column maxima, thresholds, low-quality step against the
- * (global) keys.  sph2pob_iou_assign_f32 = both on one device.  Outputs as for sph2pob_assign_f32 (argmax_overlaps,
- * gt_max_overlaps, gt_argmax_overlaps, assigned_labels may be NULL); gt_argmax_overlaps are global column indices.
- * Limits: k <= 262 140, n < 2^31 - 256, col_offset + n < 2^32 - 1.  Other variants / arithmetics: SPH2POB_ERR_OPTION (use
+ *   workspace    sph2pob_iou_assign_workspace_bytes(k, n) bytes of scratch (per-chunk column partials, per-tile row
+ *                partials): no initialisation, but untouched between reduce and finalize
+ *   state        sph2pob_iou_assign_state_bytes(k, n) bytes (per-GT accumulators + arrival counters) that must be ZERO when a
+ *                call is enqueued and are left zero by every completed call (one-call form: by the finalize pass; reduce: by
+ *                its key pass): zero the buffer once after allocation, then reuse it stream-ordered (its layout moves with
+ *                k: a buffer is clean for any (k, n) it is large enough for).  Kept apart from the scratch because the scratch's layout moves with k.
+ * sph2pob_iou_assign_f32 = one device, two launches (pairwise kernel with the reductions; finalize).  The two halves exist
+ * so that a job sharded on the box axis can put ONE all-reduce(MAX) of the k keys between them:
+ * reduce = pairwise kernel + this shard's keys; finalize = column maxima, thresholds, low-quality step against the (global)
+ * keys.  Outputs as for sph2pob_assign_f32 (argmax_overlaps, gt_max_overlaps, gt_argmax_overlaps, assigned_labels may be
+ * NULL); gt_argmax_overlaps are global column indices.
+ * Limits: k <= 262 140, n < 2^31 - 256, col_offset + n < 2^31 - 1.  Other variants / arithmetics: SPH2POB_ERR_OPTION (use
  * the two-call form on the matrix).
  */
 int64_t sph2pob_iou_assign_workspace_bytes(int64_t k, int64_t n);
+int64_t sph2pob_iou_assign_state_bytes(int64_t k, int64_t n);
 int sph2pob_iou_assign_reduce_f32(const float* gt, int64_t k, const float* boxes, int64_t n, int box_dim, int variant, int edge,
                                   const unsigned char* ignore, int64_t col_offset, float* overlaps, int64_t* gt_keys,
-                                  void* workspace, void* stream);
+                                  void* workspace, void* state, void* stream);
 int sph2pob_iou_assign_finalize_f32(const float* gt, int64_t k, const float* boxes, int64_t n, int box_dim, int variant, int edge,
                                     int64_t col_offset, const int64_t* gt_keys, float pos_iou_thr, float neg_iou_lo,
                                     float neg_iou_hi, float min_pos_iou, int match_low_quality, int gt_max_assign_all,
@@ -267,7 +275,7 @@ int sph2pob_iou_assign_f32(const float* gt, int64_t k, const float* boxes, int64
                            const unsigned char* ignore, float* overlaps, float pos_iou_thr, float neg_iou_lo, float neg_iou_hi,
                            float min_pos_iou, int match_low_quality, int gt_max_assign_all, const int64_t* gt_labels,
                            float* max_overlaps, int64_t* argmax_overlaps, float* gt_max_overlaps, int64_t* gt_argmax_overlaps,
-                           int64_t* assigned_gt_inds, int64_t* assigned_labels, int64_t* gt_keys, void* workspace, void* stream);
+                           int64_t* assigned_gt_inds, int64_t* assigned_labels, void* workspace, void* state, void* stream);
 
 /* ---- box coder: the step immediately in front of the loss when reg_decoded_bbox=True --------------
  * Replaces sphdet/bbox/coder/delta_xywh_sph_bbox_coder.py:116-161 (bbox2delta), :164-263 (delta2bbox) for box_dim 4

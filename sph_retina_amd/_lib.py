@@ -60,11 +60,12 @@ SIGNATURES = {
                            ctypes.c_void_p] + [ctypes.c_void_p] * 7 + [ctypes.c_void_p],
     'sph2pob_iou_assign_workspace_bytes': [_i64, _i64],
     'sph2pob_iou_assign_reduce_f32': [_c_f32p, _i64, _c_f32p, _i64, _int, _int, _int, ctypes.c_void_p, _i64, _c_f32p,
-                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
     'sph2pob_iou_assign_finalize_f32': [_c_f32p, _i64, _c_f32p, _i64, _int, _int, _int, _i64, ctypes.c_void_p] +
                                        [ctypes.c_float] * 4 + [_int, _int] + [ctypes.c_void_p] * 9,
     'sph2pob_iou_assign_f32': [_c_f32p, _i64, _c_f32p, _i64, _int, _int, _int, ctypes.c_void_p, _c_f32p] +
                               [ctypes.c_float] * 4 + [_int, _int] + [ctypes.c_void_p] * 10,
+    'sph2pob_iou_assign_state_bytes': [_i64, _i64],
     'sph2pob_nms_max_boxes': [],
     'sph2pob_nms_workspace_bytes': [_i64],
     'sph2pob_nms_f32': [_c_f32p, ctypes.c_void_p, _i64, _int, _int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
@@ -84,7 +85,7 @@ SIGNATURES = {
 }
 _RESTYPES = {'sph2pob_loss_sum_workspace_floats': ctypes.c_int64, 'sph2pob_target_arch': ctypes.c_char_p, 'sph2pob_error_string': ctypes.c_char_p,
              'sph2pob_nms_workspace_bytes': ctypes.c_int64, 'sph2pob_nms_segmented_workspace_bytes': ctypes.c_int64, 'sph2pob_assign_workspace_bytes': ctypes.c_int64,
-             'sph2pob_iou_assign_workspace_bytes': ctypes.c_int64}
+             'sph2pob_iou_assign_workspace_bytes': ctypes.c_int64, 'sph2pob_iou_assign_state_bytes': ctypes.c_int64}
 
 ABI_VERSION = 1
 

@@ -141,3 +141,30 @@ def loss_sum_workspace(device, n):
         if not torch.cuda.is_current_stream_capturing():
             _LOSS_WS[key] = ws
     return ws
+
+
+_ASSIGN_WS = {}
+
+
+def assign_workspace(device, nbytes, state_bytes):
+    """Per-(device, stream) buffers of the fused assigner -> (scratch, state).  `state` (per-GT accumulators + arrival counter)
+    must be zero when a call is enqueued and every call leaves it zero, so it is zero-filled once when it is (re)allocated and
+    then reused stream-ordered; both grow on demand and never shrink.  Same capture rule as sum_workspace."""
+    idx = torch.cuda.current_device() if device.index is None else device.index
+    key = (idx, raw_stream_of(device))
+    words, swords = (nbytes + 7) // 8, (state_bytes + 7) // 8
+    ws, state = _ASSIGN_WS.get(key, (None, None))
+    if ws is None or ws.numel() < words:
+        ws = torch.empty((max(words, 1 << 16),), dtype=torch.int64, device=device)
+    if state is None or state.numel() < swords:
+        state = torch.zeros((max(swords, 1 << 12),), dtype=torch.int64, device=device)
+    if not torch.cuda.is_current_stream_capturing():
+        _ASSIGN_WS[key] = (ws, state)
+    return ws, state
+
+
+def drop_assign_workspace(device):
+    """After a failed call the accumulators may be dirty: forget the cached buffers of this device."""
+    idx = torch.cuda.current_device() if device.index is None else device.index
+    for key in [k for k in _ASSIGN_WS if k[0] == idx]:
+        del _ASSIGN_WS[key]

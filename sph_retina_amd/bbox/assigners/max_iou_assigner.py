@@ -123,7 +123,6 @@ def fused_assign(gt_bboxes, bboxes, gt_labels=None, variant='standard', pos_iou_
     neg_lo, neg_hi = _thresholds(neg_iou_thr)
     max_ov = torch.empty((n,), dtype=torch.float32, device=dev)
     gt_inds = torch.empty((n,), dtype=torch.int64, device=dev)
-    keys = torch.empty((k,), dtype=torch.int64, device=dev)
     labels = gl = argmax_ov = gt_max = gt_argmax = ov = ign = None
     if gt_labels is not None:
         gl = gt_labels.to(device=dev, dtype=torch.int64).contiguous()
@@ -136,11 +135,16 @@ def fused_assign(gt_bboxes, bboxes, gt_labels=None, variant='standard', pos_iou_
         ov = torch.empty((k, n), dtype=torch.float32, device=dev)
     if ignore_mask is not None:
         ign = ignore_mask.to(device=dev, dtype=torch.uint8).contiguous()
-    ws = torch.empty((_lib.lib().sph2pob_iou_assign_workspace_bytes(k, n) // 8,), dtype=torch.int64, device=dev)
-    G.call('sph2pob_iou_assign_f32', dev, G.ptr(gt), k, G.ptr(bx), n, dim, G.VARIANTS[variant], G.EDGES[rbb_edge], G.ptr(ign),
-           G.ptr(ov), pos_iou_thr, neg_lo, neg_hi, min_pos_iou, int(bool(match_low_quality)), int(bool(gt_max_assign_all)),
-           G.ptr(gl), G.ptr(max_ov), G.ptr(argmax_ov), G.ptr(gt_max), G.ptr(gt_argmax), G.ptr(gt_inds), G.ptr(labels),
-           G.ptr(keys), G.ptr(ws), G.raw_stream_of(dev))
+    lib = _lib.lib()
+    ws, state = G.assign_workspace(dev, lib.sph2pob_iou_assign_workspace_bytes(k, n), lib.sph2pob_iou_assign_state_bytes(k, n))
+    try:
+        G.call('sph2pob_iou_assign_f32', dev, G.ptr(gt), k, G.ptr(bx), n, dim, G.VARIANTS[variant], G.EDGES[rbb_edge], G.ptr(ign),
+               G.ptr(ov), pos_iou_thr, neg_lo, neg_hi, min_pos_iou, int(bool(match_low_quality)), int(bool(gt_max_assign_all)),
+               G.ptr(gl), G.ptr(max_ov), G.ptr(argmax_ov), G.ptr(gt_max), G.ptr(gt_argmax), G.ptr(gt_inds), G.ptr(labels),
+               G.ptr(ws), G.ptr(state), G.raw_stream_of(dev))
+    except Exception:
+        G.drop_assign_workspace(dev)
+        raise
     res = AssignResult(k, gt_inds, max_ov if bboxes.dtype == torch.float32 or not bboxes.is_floating_point()
                        else max_ov.to(bboxes.dtype), labels)
     out = (res,)

@@ -386,6 +386,14 @@ __device__ __forceinline__ unsigned long long pack_max_key(float v, int64_t j) {
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
     return ((unsigned long long)u << 32) | (unsigned)(0xffffffffu - (unsigned)j);
 }
+// the fused assigner's row keys keep bit 0 of the low word free for a "this value occurs at more than one column of the
+// tile" flag: low = (0x7fffffff - index) << 1 | flag (indices < 2^31)
+__device__ __forceinline__ unsigned long long pack_row_key(float v, unsigned j) {
+    unsigned u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | ((0x7fffffffu - j) << 1);
+}
+__device__ __forceinline__ unsigned row_key_index(unsigned long long key) { return 0x7fffffffu - ((unsigned)key >> 1); }
 __device__ __forceinline__ float unpack_max_val(unsigned long long key) {
     unsigned u = (unsigned)(key >> 32);
     u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
@@ -418,10 +426,22 @@ constexpr int kPwRows = 64;
 // packed keys; culled pairs and survivors that finish to 0 are covered by the initial values: exact zeros), written once per
 // workgroup as
 //   col_part[chunk][j]      max over the chunk's rows of (IoU[i][j], first row)         (chunk = blockIdx row chunk)
-//   row_part[i][tile]       max over the tile's 256 columns of (IoU[i][j], first column, global index = col_offset + j)
+//   row_part[i][tile]       max over the tile's 256 columns of (IoU[i][j], first column, global index = col_offset + j),
+//                           bit 0 = the value may occur at more than one column of the tile
+//   row_acc[i]              atomic max of the row's partials over ALL tiles (zero before the launch)
 // `ignore` (optional, one byte per column): columns whose overlaps the assigner sets to -1 (max_iou_assigner.py:115-126)
 // — they take part in no row maximum, their column maximum is (-1, row 0), and the matrix, when written, holds -1.
-constexpr int kRowSlots = 8;   // LDS copies of a row's running maximum (lane & 7): a pass holds a few rows, 64 lanes on one address serialise
+// Per-GT accumulators of the fused assigner (the "state" buffer, zero between calls): one u64 per GT, 256 bytes apart for
+// k <= 1024 so that the GTs' atomics spread over memory channels (64 x 392 832 anchors: 70.2 -> 65.5 us, profiles/r05d_ab_fused_stride.log;
+// 16 slots per GT instead made the finalize pass read 64 KB per workgroup: slower, profiles/r05e_ab_fused_slots.log), followed by the
+// finalize pass's arrival counters: one per group of 32 column tiles + one for the groups, each on a 64-byte line (a single
+// counter serialises one returning atomic per workgroup: 1 535 tiles = +13 us, profiles/r05b_trace_fused_one_counter.txt).
+constexpr int kAccLine = 8;        // u64 words per counter line
+constexpr int kTicketGroup = 32;   // column tiles per first-level arrival counter
+__host__ __device__ inline int64_t acc_stride(int64_t k) { return k <= 1024 ? 32 : 1; }
+__host__ __device__ inline int64_t acc_words(int64_t k) { return (k * acc_stride(k) + kAccLine - 1) / kAccLine * kAccLine; }
+__host__ __device__ inline int64_t ticket_groups(int64_t tiles) { return (tiles + kTicketGroup - 1) / kTicketGroup; }
+constexpr int kRowSlots = 4;   // LDS copies of a row's running maximum (lane & 3): a pass holds a few rows, 64 lanes on one address serialise
 template <int VARIANT, int DIM, bool ARC, int OUT = 1>
 __global__ __launch_bounds__(kBlock, ARC ? 8 : 4) void iou_pairwise_compact_kernel(const float* __restrict__ b1, int m,
                                                                      const float* __restrict__ b2, int n,
@@ -430,7 +450,8 @@ __global__ __launch_bounds__(kBlock, ARC ? 8 : 4) void iou_pairwise_compact_kern
                                                                      const unsigned char* __restrict__ ignore = nullptr,
                                                                      unsigned long long* __restrict__ col_part = nullptr,
                                                                      unsigned long long* __restrict__ row_part = nullptr,
-                                                                     unsigned col_offset = 0) {
+                                                                     unsigned col_offset = 0,
+                                                                     unsigned long long* __restrict__ row_acc = nullptr) {
     constexpr bool MATRIX = (OUT & 1) != 0, REDUCE = (OUT & 2) != 0;
     __shared__ float row_raw[kPwRows][5];
     __shared__ float4 row_cull[kPwRows];
@@ -441,6 +462,9 @@ __global__ __launch_bounds__(kBlock, ARC ? 8 : 4) void iou_pairwise_compact_kern
     // the survivors are compacted — reads them by index
     __shared__ ColatTrig row_trig[kPwRows];
     __shared__ ColatTrig col_trig[kBlock];
+    __shared__ float col_raw[DIM][kBlock];   // the finishing lanes read the column's box here, not from global memory (bit-equal;
+                                             // fused 64 x 98 208: 31.2 -> 30.5 us, 64 x 392 832: 57.4 -> 53.6: profiles/r05a_ab_fused_variants.log)
+    __shared__ int row_tie[REDUCE ? kPwRows : 1];
     __shared__ unsigned long long col_key[REDUCE ? kBlock : 1];
     __shared__ unsigned long long row_key[REDUCE ? kPwRows : 1][kRowSlots];
     __shared__ unsigned long long tile_base;   // what a row holds before any survivor: (0, first live column) or (-1, first ignored one)
@@ -474,19 +498,22 @@ __global__ __launch_bounds__(kBlock, ARC ? 8 : 4) void iou_pairwise_compact_kern
     const bool ign = (REDUCE || MATRIX) && ignore != nullptr && valid && ignore[j] != 0;
     const bool live = valid & !ign;
     col_trig[threadIdx.x] = colat_trig(a[1], 2);
+#pragma unroll
+    for (int k = 0; k < DIM; k++) col_raw[k][threadIdx.x] = a[k];
     if constexpr (REDUCE) {
         col_key[threadIdx.x] = pack_max_key(ign ? -1.0f : 0.0f, r0);
         if (threadIdx.x < kPwRows * kRowSlots) (&row_key[0][0])[threadIdx.x] = 0ull;
         if (kPwRows * kRowSlots > kBlock && threadIdx.x + kBlock < kPwRows * kRowSlots) (&row_key[0][0])[threadIdx.x + kBlock] = 0ull;
         if (threadIdx.x == 0) tile_base = 0ull;
+        if (threadIdx.x < kPwRows) row_tie[threadIdx.x] = 0;
     }
     __syncthreads();
     if constexpr (REDUCE) {   // first live / first ignored column of each wave -> the tile's base key (a max over <= 8 candidates)
         const unsigned long long ml = __builtin_amdgcn_ballot_w64(live), mi = __builtin_amdgcn_ballot_w64(ign);
         if (lane == 0) {
             const int jw = bx * kBlock + wave * 64;
-            if (ml) atomicMax(&tile_base, pack_max_key(0.0f, (int64_t)col_offset + jw + __builtin_ctzll(ml)));
-            if (mi) atomicMax(&tile_base, pack_max_key(-1.0f, (int64_t)col_offset + jw + __builtin_ctzll(mi)));
+            if (ml) atomicMax(&tile_base, pack_row_key(0.0f, col_offset + jw + __builtin_ctzll(ml)));
+            if (mi) atomicMax(&tile_base, pack_row_key(-1.0f, col_offset + jw + __builtin_ctzll(mi)));
         }
     }
     const CullBox ca = cull_box(a, edge);
@@ -496,12 +523,16 @@ __global__ __launch_bounds__(kBlock, ARC ? 8 : 4) void iou_pairwise_compact_kern
         float g[5], p[5];
 #pragma unroll
         for (int k = 0; k < 5; k++) g[k] = row_raw[e.x][k];
-        load_box<DIM>(b2, e.y, p);
+#pragma unroll
+        for (int k = 0; k < 5; k++) p[k] = k < DIM ? col_raw[k < DIM ? k : 0][e.y - bx * kBlock] : 0.0f;
         const float v = lean_finish<VARIANT, DIM, 1>(g, p, mode, edge, row_trig[e.x], col_trig[e.y - bx * kBlock]);
         if constexpr (MATRIX) out[(int64_t)(r0 + e.x) * n + e.y] = v;
         if constexpr (REDUCE) if (!(v <= 0.0f)) {   // > 0 or NaN: zeros are the initial values
             atomicMax(&col_key[e.y - bx * kBlock], pack_max_key(v, r0 + e.x));
-            atomicMax(&row_key[e.x][lane & (kRowSlots - 1)], pack_max_key(v, (int64_t)col_offset + e.y));
+            // the value already in the slot (a column of this row finished earlier) — equal value bits = a tie inside the tile
+            const unsigned long long key = pack_row_key(v, col_offset + e.y);
+            const unsigned long long old = atomicMax(&row_key[e.x][lane & (kRowSlots - 1)], key);
+            if ((unsigned)(old >> 32) == (unsigned)(key >> 32)) row_tie[e.x] = 1;
         }
     };
     float* orow = out + (int64_t)r0 * n + j;   // this column's element of the tile's first row (cull rows at a higher
@@ -543,7 +574,16 @@ __global__ __launch_bounds__(kBlock, ARC ? 8 : 4) void iou_pairwise_compact_kern
             unsigned long long best = tile_base;
 #pragma unroll
             for (int t = 0; t < kRowSlots; t++) { const unsigned long long v = row_key[threadIdx.x][t]; best = v > best ? v : best; }
-            row_part[(int64_t)(r0 + threadIdx.x) * gridDim.x + bx] = best;
+            int same = 0;   // slots that hold the maximum VALUE (each at a column of its own)
+#pragma unroll
+            for (int t = 0; t < kRowSlots; t++) same += (unsigned)(row_key[threadIdx.x][t] >> 32) == (unsigned)(best >> 32);
+            // flag: conservative (a tie seen at a lower value also sets it; the finalize pass then only re-evaluates for nothing)
+            row_part[(int64_t)(r0 + threadIdx.x) * gridDim.x + bx] = best | (unsigned long long)(row_tie[threadIdx.x] | (same > 1));
+            // the row's running maximum over all tiles: relaxed device-scope atomic, only from tiles that hold something
+            // above the rows' common floor (0 at the shard's first column) — with an ignore mask the floor is not known
+            // here, and every tile contributes
+            if (ignore != nullptr || (unsigned)(best >> 32) > 0x80000000u)
+                __hip_atomic_fetch_max(row_acc + (r0 + threadIdx.x) * acc_stride(m), best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -1167,45 +1207,37 @@ __global__ __launch_bounds__(kBlock) void assign_finalize_kernel(const float* __
 }
 
 // ---- fused assigner (no k x n matrix): phase 2 and 3 behind iou_pairwise_compact_kernel<.., OUT & 2> ----
-// B': one workgroup per row (GT): maximum of the row's per-tile partials -> one signed-order key per GT (what a job
-// sharded on the box axis all-reduces with MAX)
-__global__ __launch_bounds__(kBlock) void assign_row_keys_kernel(const unsigned long long* __restrict__ partial, int nparts,
-                                                                long long* __restrict__ gt_keys) {
-    __shared__ unsigned long long sm[kBlock / 64];
-    const int i = blockIdx.x;
-    unsigned long long best = 0ull;
-    for (int p0 = threadIdx.x; p0 < nparts; p0 += kBlock * 8) {
-        unsigned long long v[8];
-#pragma unroll
-        for (int t = 0; t < 8; t++) {
-            const int p = p0 + t * kBlock;
-            v[t] = partial[(int64_t)i * nparts + (p < nparts ? p : nparts - 1)];
-        }
-#pragma unroll
-        for (int t = 0; t < 8; t++) best = v[t] > best ? v[t] : best;
-    }
-    best = wave_max_u64(best);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = best;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int w = 1; w < kBlock / 64; w++) best = sm[w] > best ? sm[w] : best;
-        gt_keys[i] = key_to_signed(best);
+// the rows' floor: what a row holds when no tile contributed (no ignore mask: IoU 0 at the shard's first column)
+__device__ __forceinline__ unsigned long long row_floor(bool has_ignore, unsigned col_offset) {
+    return has_ignore ? 0ull : pack_row_key(0.0f, col_offset);
+}
+// B' (the sharded form only): accumulators -> signed-order keys for the all-reduce; leaves the accumulators zero
+__global__ __launch_bounds__(kBlock) void assign_keys_from_acc_kernel(unsigned long long* __restrict__ row_acc, int k, bool has_ignore,
+                                                                     unsigned col_offset, long long* __restrict__ gt_keys) {
+    const unsigned long long fl = row_floor(has_ignore, col_offset);
+    for (int i = threadIdx.x; i < k; i += kBlock) {
+        const unsigned long long a = row_acc[i * acc_stride(k)];
+        gt_keys[i] = key_to_signed((a > fl ? a : fl) & ~1ull);
+        row_acc[i * acc_stride(k)] = 0ull;
     }
 }
 // C': one workgroup per column tile (the tiles of phase 1).  Column maxima from the row chunks' partials, thresholds, and
 // the low-quality step (max_iou_assigner.py:192-207) without the matrix: `overlaps[i, :] == gt_max[i]` can hold in this tile
 //   * for gt_max[i] == 0 on every column that is not ignored (nothing overlaps GT i: every live IoU of the row is 0);
 //   * for gt_max[i] == -1 on every ignored column (the whole row is ignored columns);
-//   * for gt_max[i] > 0 only if the TILE's maximum of row i (row_part, still in the workspace) equals it — then, and only
-//     then, the row is evaluated again against the tile's 256 columns with the very functions phase 1 ran (same inputs, same
-//     bits): a handful of (row, tile) pairs per call.
+//   * for gt_max[i] > 0 only if the TILE's maximum of row i (row_part, still in the workspace) equals it — then at the
+//     column the partial names and, only when phase 1 saw the value at a second column of the tile (bit 0 of the partial:
+//     duplicated boxes, mirror-symmetric anchors), wherever a re-evaluation of the row against the tile's 256 columns with
+//     the very functions phase 1 ran (same inputs, same bits) finds it.
 // Later GTs overwrite earlier ones in the reference's loop: the largest matching i wins.
-template <int VARIANT, int DIM, bool ARC>
+// FROM_ACC: the per-GT keys are phase 1's accumulators (one device); the last workgroup to finish zeroes them and the arrival
+// counter for the next call.  Otherwise they are `gt_keys` (all-reduced by the caller).
+template <int VARIANT, int DIM, bool ARC, bool FROM_ACC>
 __global__ __launch_bounds__(kBlock) void assign_fused_finalize_kernel(const float* __restrict__ b1, int k, const float* __restrict__ b2, int n,
                                                                       int edge_arg, const unsigned long long* __restrict__ col_part, int chunks,
                                                                       const unsigned long long* __restrict__ row_part,
-                                                                      const long long* __restrict__ gt_keys, unsigned col_offset,
+                                                                      const long long* __restrict__ gt_keys, unsigned long long* __restrict__ row_acc,
+                                                                      bool has_ignore, unsigned col_offset,
                                                                       float pos_thr, float neg_lo, float neg_hi, float min_pos,
                                                                       int low_quality, int assign_all,
                                                                       const int64_t* __restrict__ gt_labels,
@@ -1218,11 +1250,16 @@ __global__ __launch_bounds__(kBlock) void assign_fused_finalize_kernel(const flo
     const int jraw = tile * kBlock + threadIdx.x;
     const bool valid = jraw < n;
     const int j = valid ? jraw : n - 1;
+    const unsigned long long fl = row_floor(has_ignore, col_offset);
+    auto row_key_of = [&](int i) -> unsigned long long {
+        if (FROM_ACC) { const unsigned long long a = row_acc[i * acc_stride(k)]; return (a > fl ? a : fl) & ~1ull; }
+        return key_from_signed(gt_keys[i]);
+    };
     if (tile == 0 && gt_max) {   // the per-GT results, decoded once
         for (int i = threadIdx.x; i < k; i += kBlock) {
-            const unsigned long long key = key_from_signed(gt_keys[i]);
+            const unsigned long long key = row_key_of(i);
             gt_max[i] = unpack_max_val(key);
-            if (gt_argmax) gt_argmax[i] = (int64_t)(0xffffffffu - (unsigned)key);
+            if (gt_argmax) gt_argmax[i] = (int64_t)row_key_index(key);
         }
     }
     unsigned long long ck = 0ull;
@@ -1243,8 +1280,8 @@ __global__ __launch_bounds__(kBlock) void assign_fused_finalize_kernel(const flo
         int best = -1;
         if (!assign_all) {
             for (int i = 0; i < k; i++) {
-                const unsigned long long key = key_from_signed(gt_keys[i]);
-                if (unpack_max_val(key) >= min_pos && (0xffffffffu - (unsigned)key) == col_offset + (unsigned)j) best = i;
+                const unsigned long long key = row_key_of(i);
+                if (unpack_max_val(key) >= min_pos && row_key_index(key) == col_offset + (unsigned)j) best = i;
             }
         } else {
             float a5[5] = {0.0f, 0.0f, 1.0f, 1.0f, 0.0f};
@@ -1253,15 +1290,23 @@ __global__ __launch_bounds__(kBlock) void assign_fused_finalize_kernel(const flo
             ColatTrig ct{};
             for (int r0 = 0; r0 < k; r0 += 64) {
                 const int il = r0 + lane, ic = il < k ? il : k - 1;
-                const unsigned long long gk = key_from_signed(gt_keys[ic]);
+                const unsigned long long gk = row_key_of(ic);
                 const float g = unpack_max_val(gk);
                 const bool on = il < k && g >= min_pos;
                 const unsigned long long zero = __builtin_amdgcn_ballot_w64(on && g == 0.0f);
                 const unsigned long long neg = __builtin_amdgcn_ballot_w64(on && g == -1.0f);
                 const unsigned long long pk = row_part[(int64_t)ic * tiles + tile];
-                unsigned long long rec = __builtin_amdgcn_ballot_w64(on && g > 0.0f && (unsigned)(pk >> 32) == (unsigned)(gk >> 32));
+                const bool here = on && g > 0.0f && (unsigned)(pk >> 32) == (unsigned)(gk >> 32);   // the row's maximum lives in this tile
+                unsigned long long rec = __builtin_amdgcn_ballot_w64(here && (pk & 1ull));              // ... maybe at several columns
+                unsigned long long one = __builtin_amdgcn_ballot_w64(here && !(pk & 1ull));             // ... at the one the partial names
                 if (!ign && zero) best = r0 + 63 - __builtin_clzll(zero);
                 if (ign && neg) { const int t = r0 + 63 - __builtin_clzll(neg); best = t > best ? t : best; }
+                while (one) {   // wave-uniform; descending, so the first hit is the largest row
+                    const int t = 63 - __builtin_clzll(one);
+                    one &= ~(1ull << t);
+                    const unsigned col = row_key_index(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)pk, t)));
+                    if (valid && col == col_offset + (unsigned)j && r0 + t > best) best = r0 + t;
+                }
                 while (rec) {   // wave-uniform: rows whose maximum lives in this tile
                     const int t = __builtin_ctzll(rec);
                     rec &= rec - 1;
@@ -1283,11 +1328,33 @@ __global__ __launch_bounds__(kBlock) void assign_fused_finalize_kernel(const flo
         }
         if (best >= 0) a = best + 1;
     }
-    if (!valid) return;
-    max_ov[j] = m;
-    if (argmax_ov) argmax_ov[j] = am;
-    gt_inds[j] = a;
-    if (labels) labels[j] = a > 0 ? gt_labels[a - 1] : -1;
+    if (valid) {
+        max_ov[j] = m;
+        if (argmax_ov) argmax_ov[j] = am;
+        gt_inds[j] = a;
+        if (labels) labels[j] = a > 0 ? gt_labels[a - 1] : -1;
+    }
+    if (FROM_ACC) {   // every read of the accumulators above has returned (its value was used); the last arrival cleans up.
+        // Two levels of arrival counters (a returning atomic per workgroup on ONE address serialises): the last of each group of
+        // 32 tiles reports to the top counter, the last group to report zeroes the accumulators and every counter.
+        __shared__ unsigned ticket;
+        unsigned long long* counters = row_acc + acc_words(k);   // [0]: top, [1 + g]: group g, kAccLine words apart
+        const int groups = (int)ticket_groups(tiles), grp = tile / kTicketGroup;
+        const int members = grp == groups - 1 ? tiles - grp * kTicketGroup : kTicketGroup;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned t = __hip_atomic_fetch_add((unsigned*)(counters + (int64_t)(1 + grp) * kAccLine), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned last = 0;
+            if ((int)t == members - 1)
+                last = (int)__hip_atomic_fetch_add((unsigned*)counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1;
+            ticket = last;
+        }
+        __syncthreads();
+        if (ticket) {
+            for (int i = threadIdx.x; i < k; i += kBlock) row_acc[i * acc_stride(k)] = 0ull;
+            for (int i = threadIdx.x; i <= groups; i += kBlock) counters[(int64_t)i * kAccLine] = 0ull;
+        }
+    }
 }
 
 // ---- adjoint of the Sph2Pob transform: gradients of the planar boxes -> gradients of the spherical boxes ----
@@ -1424,11 +1491,11 @@ struct PairwiseLaunch {
             if (edge == SPH2POB_EDGE_ARC)
                 hipLaunchKernelGGL((iou_pairwise_compact_kernel<V >= 2 ? 0 : V, D, true, 1>), grid, dim3(kBlock), 0, s, b1, (int)m, b2, (int)n,
                                    out, mode, edge, (int)rpw, (const unsigned char*)nullptr, (unsigned long long*)nullptr,
-                                   (unsigned long long*)nullptr, 0u);
+                                   (unsigned long long*)nullptr, 0u, (unsigned long long*)nullptr);
             else
                 hipLaunchKernelGGL((iou_pairwise_compact_kernel<V >= 2 ? 0 : V, D, false, 1>), grid, dim3(kBlock), 0, s, b1, (int)m, b2, (int)n,
                                    out, mode, edge, (int)rpw, (const unsigned char*)nullptr, (unsigned long long*)nullptr,
-                                   (unsigned long long*)nullptr, 0u);
+                                   (unsigned long long*)nullptr, 0u, (unsigned long long*)nullptr);
             return launch_status();
         }
         // grid.y is limited to 65535 rows per launch: walk the rows in slabs
@@ -1452,49 +1519,53 @@ struct PairwiseLaunch {
     }
 };
 // the fused assigner's two halves (closed-form standard / efficient only: the kernels that carry the reductions)
-struct AssignWs { unsigned long long *col_part, *row_part; int64_t chunks, tiles; };
-static AssignWs assign_ws(void* workspace, int64_t k, int64_t n) {
+struct AssignWs { unsigned long long *row_acc, *col_part, *row_part; int64_t chunks, tiles; };
+static AssignWs assign_ws(void* workspace, void* state, int64_t k, int64_t n) {
     AssignWs w;
     w.tiles = (n + kBlock - 1) / kBlock;
     const int64_t rpw = pairwise_rows_per_wg(k, n);
     w.chunks = (k + rpw - 1) / rpw;
+    w.row_acc = (unsigned long long*)state;   // k accumulators + the arrival counter: zero between calls
     w.col_part = (unsigned long long*)workspace;
     w.row_part = w.col_part + w.chunks * n;
     return w;
 }
 struct AssignReduceLaunch {
     const float* b1; int64_t m; const float* b2; int64_t n; float* out; int edge; const unsigned char* ignore; unsigned col_offset;
-    long long* gt_keys; void* workspace; hipStream_t s; bool fast = true;
+    long long* gt_keys /* NULL: leave the keys in the accumulators */; void* workspace; void* state; hipStream_t s; bool fast = true;
     template <int V, int D> int run() {
         if constexpr (V >= 2) return SPH2POB_ERR_OPTION;
         else {
             if (!fast) return SPH2POB_ERR_OPTION;
-            const AssignWs w = assign_ws(workspace, m, n);
+            const AssignWs w = assign_ws(workspace, state, m, n);
             const int64_t rpw = pairwise_rows_per_wg(m, n);
             dim3 grid((unsigned)w.tiles, (unsigned)w.chunks);
 #define SPH_AR(ARC, OUT) hipLaunchKernelGGL((iou_pairwise_compact_kernel<V, D, ARC, OUT>), grid, dim3(kBlock), 0, s, b1, (int)m, b2, (int)n, out, \
-                                           (int)MODE_IOU, edge, (int)rpw, ignore, w.col_part, w.row_part, col_offset)
+                                           (int)MODE_IOU, edge, (int)rpw, ignore, w.col_part, w.row_part, col_offset, w.row_acc)
             if (edge == SPH2POB_EDGE_ARC) { if (out) SPH_AR(true, 3); else SPH_AR(true, 2); }
             else { if (out) SPH_AR(false, 3); else SPH_AR(false, 2); }
 #undef SPH_AR
-            hipLaunchKernelGGL(assign_row_keys_kernel, dim3((unsigned)m), dim3(kBlock), 0, s, w.row_part, (int)w.tiles, gt_keys);
+            if (gt_keys)
+                hipLaunchKernelGGL(assign_keys_from_acc_kernel, dim3(1), dim3(kBlock), 0, s, w.row_acc, (int)m, ignore != nullptr, col_offset, gt_keys);
             return launch_status();
         }
     }
 };
 struct AssignFinalizeLaunch {
-    const float* b1; int64_t m; const float* b2; int64_t n; int edge; unsigned col_offset; const long long* gt_keys;
+    const float* b1; int64_t m; const float* b2; int64_t n; int edge; unsigned col_offset; const long long* gt_keys /* NULL: the accumulators */;
+    bool has_ignore;
     float pos, neg_lo, neg_hi, min_pos; int low_quality, assign_all; const int64_t* gt_labels; float* max_ov; int64_t* argmax_ov;
-    float* gt_max; int64_t* gt_argmax; int64_t* gt_inds; int64_t* labels; void* workspace; hipStream_t s; bool fast = true;
+    float* gt_max; int64_t* gt_argmax; int64_t* gt_inds; int64_t* labels; void* workspace; void* state; hipStream_t s; bool fast = true;
     template <int V, int D> int run() {
         if constexpr (V >= 2) return SPH2POB_ERR_OPTION;
         else {
             if (!fast) return SPH2POB_ERR_OPTION;
-            const AssignWs w = assign_ws(workspace, m, n);
-#define SPH_AF(ARC) hipLaunchKernelGGL((assign_fused_finalize_kernel<V, D, ARC>), dim3((unsigned)w.tiles), dim3(kBlock), 0, s, b1, (int)m, b2, (int)n, \
-                                      edge, w.col_part, (int)w.chunks, w.row_part, gt_keys, col_offset, pos, neg_lo, neg_hi, min_pos, low_quality,  \
-                                      assign_all, gt_labels, max_ov, argmax_ov, gt_max, gt_argmax, gt_inds, labels)
-            if (edge == SPH2POB_EDGE_ARC) SPH_AF(true); else SPH_AF(false);
+            const AssignWs w = assign_ws(workspace, state, m, n);
+#define SPH_AF(ARC, ACC) hipLaunchKernelGGL((assign_fused_finalize_kernel<V, D, ARC, ACC>), dim3((unsigned)w.tiles), dim3(kBlock), 0, s, b1, (int)m, b2, \
+                                           (int)n, edge, w.col_part, (int)w.chunks, w.row_part, gt_keys, w.row_acc, has_ignore, col_offset, pos, neg_lo,  \
+                                           neg_hi, min_pos, low_quality, assign_all, gt_labels, max_ov, argmax_ov, gt_max, gt_argmax, gt_inds, labels)
+            if (edge == SPH2POB_EDGE_ARC) { if (gt_keys) SPH_AF(true, false); else SPH_AF(true, true); }
+            else { if (gt_keys) SPH_AF(false, false); else SPH_AF(false, true); }
 #undef SPH_AF
             return launch_status();
         }
@@ -1826,8 +1897,11 @@ int sph2pob_assign_f32(const float* overlaps, int64_t k, int64_t n, float pos_io
 
 int64_t sph2pob_iou_assign_workspace_bytes(int64_t k, int64_t n) {
     if (k <= 0 || n <= 0) return 0;
-    const AssignWs w = assign_ws(nullptr, k, n);
+    const AssignWs w = assign_ws(nullptr, nullptr, k, n);
     return (w.chunks * n + k * w.tiles) * 8;
+}
+int64_t sph2pob_iou_assign_state_bytes(int64_t k, int64_t n) {
+    return k > 0 && n > 0 ? (acc_words(k) + (1 + ticket_groups((n + kBlock - 1) / kBlock)) * kAccLine) * 8 : 0;
 }
 
 static int assign_fused_check(int64_t k, int64_t n, int box_dim, int variant, int edge, int64_t col_offset) {
@@ -1835,19 +1909,19 @@ static int assign_fused_check(int64_t k, int64_t n, int box_dim, int variant, in
     if (rc) return rc;
     if ((variant & 0xff) > SPH2POB_VARIANT_EFFICIENT || (variant & SPH2POB_FLAG_REFERENCE_ORDER)) return SPH2POB_ERR_OPTION;
     if (k <= 0 || n <= 0 || n >= ((int64_t)1 << 31) - kBlock || k > (int64_t)65535 * 4 || col_offset < 0 ||
-        col_offset + n > (int64_t)0xfffffffe)
+        col_offset + n > (int64_t)0x7ffffffe)
         return SPH2POB_ERR_SIZE;
     return SPH2POB_OK;
 }
 
 int sph2pob_iou_assign_reduce_f32(const float* gt, int64_t k, const float* boxes, int64_t n, int box_dim, int variant, int edge,
                                   const unsigned char* ignore, int64_t col_offset, float* overlaps, int64_t* gt_keys,
-                                  void* workspace, void* stream) {
+                                  void* workspace, void* state, void* stream) {
     int rc = assign_fused_check(k, n, box_dim, variant, edge, col_offset);
     if (rc) return rc;
-    if (!gt || !boxes || !gt_keys || !workspace) return SPH2POB_ERR_NULL;
+    if (!gt || !boxes || !gt_keys || !workspace || !state) return SPH2POB_ERR_NULL;
     return dispatch(variant, box_dim, AssignReduceLaunch{gt, k, boxes, n, overlaps, edge, ignore, (unsigned)col_offset,
-                                                         (long long*)gt_keys, workspace, (hipStream_t)stream});
+                                                         (long long*)gt_keys, workspace, state, (hipStream_t)stream});
 }
 
 int sph2pob_iou_assign_finalize_f32(const float* gt, int64_t k, const float* boxes, int64_t n, int box_dim, int variant, int edge,
@@ -1861,23 +1935,28 @@ int sph2pob_iou_assign_finalize_f32(const float* gt, int64_t k, const float* box
     if (!gt || !boxes || !gt_keys || !workspace || !max_overlaps || !assigned_gt_inds || (assigned_labels && !gt_labels))
         return SPH2POB_ERR_NULL;
     return dispatch(variant, box_dim,
-                    AssignFinalizeLaunch{gt, k, boxes, n, edge, (unsigned)col_offset, (const long long*)gt_keys, pos_iou_thr,
+                    AssignFinalizeLaunch{gt, k, boxes, n, edge, (unsigned)col_offset, (const long long*)gt_keys, false, pos_iou_thr,
                                          neg_iou_lo, neg_iou_hi, min_pos_iou, match_low_quality, gt_max_assign_all, gt_labels,
                                          max_overlaps, argmax_overlaps, gt_max_overlaps, gt_argmax_overlaps, assigned_gt_inds,
-                                         assigned_labels, workspace, (hipStream_t)stream});
+                                         assigned_labels, workspace, nullptr, (hipStream_t)stream});
 }
 
 int sph2pob_iou_assign_f32(const float* gt, int64_t k, const float* boxes, int64_t n, int box_dim, int variant, int edge,
                            const unsigned char* ignore, float* overlaps, float pos_iou_thr, float neg_iou_lo, float neg_iou_hi,
                            float min_pos_iou, int match_low_quality, int gt_max_assign_all, const int64_t* gt_labels,
                            float* max_overlaps, int64_t* argmax_overlaps, float* gt_max_overlaps, int64_t* gt_argmax_overlaps,
-                           int64_t* assigned_gt_inds, int64_t* assigned_labels, int64_t* gt_keys, void* workspace, void* stream) {
-    int rc = sph2pob_iou_assign_reduce_f32(gt, k, boxes, n, box_dim, variant, edge, ignore, 0, overlaps, gt_keys, workspace, stream);
+                           int64_t* assigned_gt_inds, int64_t* assigned_labels, void* workspace, void* state, void* stream) {
+    int rc = assign_fused_check(k, n, box_dim, variant, edge, 0);
     if (rc) return rc;
-    return sph2pob_iou_assign_finalize_f32(gt, k, boxes, n, box_dim, variant, edge, 0, gt_keys, pos_iou_thr, neg_iou_lo, neg_iou_hi,
-                                           min_pos_iou, match_low_quality, gt_max_assign_all, gt_labels, max_overlaps,
-                                           argmax_overlaps, gt_max_overlaps, gt_argmax_overlaps, assigned_gt_inds,
-                                           assigned_labels, workspace, stream);
+    if (!gt || !boxes || !workspace || !state || !max_overlaps || !assigned_gt_inds || (assigned_labels && !gt_labels)) return SPH2POB_ERR_NULL;
+    // two launches: the per-GT keys stay in the workspace's accumulators, the finalize pass reads and clears them
+    rc = dispatch(variant, box_dim, AssignReduceLaunch{gt, k, boxes, n, overlaps, edge, ignore, 0u, nullptr, workspace, state, (hipStream_t)stream});
+    if (rc) return rc;
+    return dispatch(variant, box_dim,
+                    AssignFinalizeLaunch{gt, k, boxes, n, edge, 0u, nullptr, ignore != nullptr, pos_iou_thr, neg_iou_lo, neg_iou_hi,
+                                         min_pos_iou, match_low_quality, gt_max_assign_all, gt_labels, max_overlaps, argmax_overlaps,
+                                         gt_max_overlaps, gt_argmax_overlaps, assigned_gt_inds, assigned_labels, workspace, state,
+                                         (hipStream_t)stream});
 }
 
 int sph2pob_transform_bwd_f32(const float* b1, const float* b2, const float* grad_planar1, const float* grad_planar2,

@@ -228,8 +228,10 @@ def test_fused_two_shards_with_key_exchange_equal_one_device(A):
         sh = boxes[lo:hi].contiguous()
         n = hi - lo
         ws = torch.empty((lib.sph2pob_iou_assign_workspace_bytes(40, n) // 8,), dtype=torch.int64, device='cuda')
+        state = torch.zeros((lib.sph2pob_iou_assign_state_bytes(40, n) // 8,), dtype=torch.int64, device='cuda')
         key = torch.empty((40,), dtype=torch.int64, device='cuda')
-        rc = lib.sph2pob_iou_assign_reduce_f32(G.ptr(gt), 40, G.ptr(sh), n, 4, 0, 0, None, lo, None, G.ptr(key), G.ptr(ws), st)
+        rc = lib.sph2pob_iou_assign_reduce_f32(G.ptr(gt), 40, G.ptr(sh), n, 4, 0, 0, None, lo, None, G.ptr(key), G.ptr(ws), G.ptr(state), st)
+        assert int(state.abs().sum()) == 0      # left clean
         assert rc == 0
         keys.append(key); wss.append(ws); shards.append(sh)
     allk = torch.maximum(keys[0], keys[1])    # all_reduce(MAX) on int64

@@ -164,6 +164,27 @@ def config4(h=512, w=1024):
     t_fused = timeit(lambda: fused.assign(anchors, gt, gt_labels=labels))
     matrix = SphMaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0, ignore_iof_thr=-1, fused=False)
     t_matrix = timeit(lambda: matrix.assign(anchors, gt, gt_labels=labels))
+    # the same two routes through the C ABI with every buffer allocated once (what a captured graph or a C++ caller pays)
+    from sph_retina_amd import _lib, _torch_glue as G
+    lib = _lib.lib()
+    kk, nn = gt.size(0), anchors.size(0)
+    st = G.raw_stream_of(gt.device)
+    mo, gi, lab = torch.empty(nn, device='cuda'), torch.empty(nn, dtype=torch.int64, device='cuda'), torch.empty(nn, dtype=torch.int64, device='cuda')
+    amo, gm, gam = torch.empty(nn, dtype=torch.int64, device='cuda'), torch.empty(kk, device='cuda'), torch.empty(kk, dtype=torch.int64, device='cuda')
+    wsf = torch.empty(lib.sph2pob_iou_assign_workspace_bytes(kk, nn) // 8, dtype=torch.int64, device='cuda')
+    stf = torch.zeros(lib.sph2pob_iou_assign_state_bytes(kk, nn) // 8, dtype=torch.int64, device='cuda')
+    wsm = torch.empty(lib.sph2pob_assign_workspace_bytes(kk, nn) // 8, dtype=torch.int64, device='cuda')
+    ovb = torch.empty((kk, nn), device='cuda')
+
+    def fused_abi():
+        lib.sph2pob_iou_assign_f32(G.ptr(gt), kk, G.ptr(anchors), nn, 4, 0, 0, None, None, 0.5, 0.0, 0.4, 0.0, 1, 1, G.ptr(labels),
+                                   G.ptr(mo), None, None, None, G.ptr(gi), G.ptr(lab), G.ptr(wsf), G.ptr(stf), st)
+
+    def matrix_abi():
+        lib.sph2pob_iou_pairwise_f32(G.ptr(gt), kk, G.ptr(anchors), nn, G.ptr(ovb), 4, 0, 0, 0, 0, st)
+        lib.sph2pob_assign_f32(G.ptr(ovb), kk, nn, 0.5, 0.0, 0.4, 0.0, 1, 1, G.ptr(labels), G.ptr(mo), G.ptr(amo), G.ptr(gm),
+                               G.ptr(gam), G.ptr(gi), G.ptr(lab), G.ptr(wsm), st)
+    t_fused_abi, t_matrix_abi = timeit(fused_abi, reps=200), timeit(matrix_abi, reps=200)
     k = 5000
     rng = np.random.default_rng(4)
     centres = boxes(300, 8, alpha=(5, 60)).cpu().numpy()
@@ -179,7 +200,8 @@ def config4(h=512, w=1024):
     m, n = ov.shape
     return {'config': 'configs[3]: MaxIoUAssigner overlaps 64 GT x %d anchors (%dx%d ERP grid) + SphNMS 5000 boxes' % (n, h, w),
             'pairs': m * n, 'iou_matrix_ms': t_iou * 1e3, 'pairs_per_s': m * n / t_iou,
-            'iou_plus_torch_max_argmax_ms': t_assign * 1e3, 'fused_assign_total_ms': t_fused * 1e3, 'matrix_assign_total_ms': t_matrix * 1e3, 'frac_pairs_overlapping': float((ov > 0).float().mean()),
+            'iou_plus_torch_max_argmax_ms': t_assign * 1e3, 'fused_assign_total_ms': t_fused * 1e3, 'matrix_assign_total_ms': t_matrix * 1e3,
+            'fused_assign_c_abi_ms': t_fused_abi * 1e3, 'matrix_assign_c_abi_ms': t_matrix_abi * 1e3, 'frac_pairs_overlapping': float((ov > 0).float().mean()),
             'nms_5000x37cls_ms': t_nms * 1e3, 'nms_5000_single_class_ms': t_nms1 * 1e3}
 
 
@@ -261,5 +283,8 @@ def variants(n=1_000_000):
 if __name__ == '__main__':
     # config4 twice: the reference's default 512 x 1024 ERP (98 208 anchors: the "~100k" of BASELINE configs[3]) and the
     # literal 1024 x 2048 grid (392 832 anchors, SURVEY §8d "secondary")
-    for fn in (config3, config4, lambda: config4(1024, 2048), coder, unbiased, variants):
-        print(json.dumps(fn()), flush=True)
+    # (arguments select configurations by name: config3 config4 config4b coder unbiased variants; none = all)
+    table = dict(config3=config3, config4=config4, config4b=lambda: config4(1024, 2048), coder=coder, unbiased=unbiased,
+                 variants=variants)
+    for name in (sys.argv[1:] or list(table)):
+        print(json.dumps(table[name]()), flush=True)
