@@ -77,3 +77,90 @@ def sharded_pairwise_iou(gt_bboxes, anchors_shard, op='sph2pob_standard_iou', ga
     if not gather:
         return local
     return gather_shards(local.t().contiguous(), counts, group).t()
+
+
+# ---- sharded MaxIoUAssigner ("per-anchor max local; per-GT max = all_reduce(MAX) of k values + index resolution") ----
+def pack_assign_keys(values, indices):
+    """Per-GT (max IoU, global column) as int64 keys whose SIGNED order is (value ascending, then index DESCENDING), so that
+    `all_reduce(MAX)` yields the maximum value and, among equal values, the smallest global column — `torch.max(dim=1)` of the
+    unsharded matrix.  The exchange format of `sph2pob_iou_assign_reduce_f32` / `_finalize_f32` (include/sph2pob_hip.h):
+    high word = the float's bits mapped to an order-preserving int32, low word = (0x7fffffff - index) << 1."""
+    bits = values.contiguous().view(torch.int32).to(torch.int64)
+    hi = torch.where(bits >= 0, bits, ~(bits & 0x7fffffff))
+    return (hi << 32) | ((0x7fffffff - indices.to(torch.int64)) << 1)
+
+
+def unpack_assign_keys(keys):
+    """-> (values fp32, global column indices int64)."""
+    hi = keys >> 32                                                     # arithmetic shift: the signed high word
+    bits = torch.where(hi >= 0, hi, (~hi) | 0x80000000)                 # back to the float's bit pattern (as 0 .. 2^32 - 1)
+    values = torch.where(bits >= 0x80000000, bits - (1 << 32), bits).to(torch.int32).view(torch.float32)
+    return values, 0x7fffffff - ((keys & 0xffffffff) >> 1)
+
+
+class _HipAssignOp:
+    """The per-shard operator on the MI355X: the two halves of the fused assigner through the C ABI."""
+
+    def __init__(self, variant='standard', rbb_edge='arc'):
+        self.variant, self.rbb_edge = variant, rbb_edge
+
+    def reduce(self, gt, shard, col_offset, ignore_mask=None):
+        from . import _lib, _torch_glue as G
+        lib = _lib.lib()
+        G.require_hip(gt, shard)
+        gt, shard = G.as_f32_nograd(gt), G.as_f32_nograd(shard)
+        k, n, dim = gt.size(0), shard.size(0), gt.size(1)
+        dev = shard.device
+        ws, state = G.assign_workspace(dev, lib.sph2pob_iou_assign_workspace_bytes(k, n), lib.sph2pob_iou_assign_state_bytes(k, n))
+        keys = torch.empty((k,), dtype=torch.int64, device=dev)
+        ign = None if ignore_mask is None else ignore_mask.to(device=dev, dtype=torch.uint8).contiguous()
+        try:
+            G.call('sph2pob_iou_assign_reduce_f32', dev, G.ptr(gt), k, G.ptr(shard), n, dim, G.VARIANTS[self.variant],
+                   G.EDGES[self.rbb_edge], G.ptr(ign), int(col_offset), None, G.ptr(keys), G.ptr(ws), G.ptr(state), G.raw_stream_of(dev))
+        except Exception:
+            G.drop_assign_workspace(dev)
+            raise
+        return keys, (gt, shard, int(col_offset), ws)
+
+    def finalize(self, ctx, keys, gt_labels, pos_iou_thr, neg_lo, neg_hi, min_pos_iou, match_low_quality, gt_max_assign_all):
+        from . import _torch_glue as G
+        gt, shard, col_offset, ws = ctx
+        k, n, dim = gt.size(0), shard.size(0), gt.size(1)
+        dev = shard.device
+        max_ov = torch.empty((n,), dtype=torch.float32, device=dev)
+        gt_inds = torch.empty((n,), dtype=torch.int64, device=dev)
+        labels = gl = None
+        if gt_labels is not None:
+            gl = gt_labels.to(device=dev, dtype=torch.int64).contiguous()
+            labels = torch.empty((n,), dtype=torch.int64, device=dev)
+        G.call('sph2pob_iou_assign_finalize_f32', dev, G.ptr(gt), k, G.ptr(shard), n, dim, G.VARIANTS[self.variant],
+               G.EDGES[self.rbb_edge], col_offset, G.ptr(keys), pos_iou_thr, neg_lo, neg_hi, min_pos_iou, int(bool(match_low_quality)),
+               int(bool(gt_max_assign_all)), G.ptr(gl), G.ptr(max_ov), None, None, None, G.ptr(gt_inds), G.ptr(labels), G.ptr(ws),
+               G.raw_stream_of(dev))
+        return gt_inds, max_ov, labels
+
+
+def sharded_assign(gt_bboxes, anchors_shard, col_offset, gt_labels=None, pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0.0,
+                   gt_max_assign_all=True, match_low_quality=True, ignore_mask=None, op='standard', group=None):
+    """`MaxIoUAssigner.assign` (mmdet/core/bbox/assigners/max_iou_assigner.py:113, :135-220) for THIS RANK's slice of the
+    anchor axis, equal to the slice [col_offset, col_offset + n_r) of the single-process result bit for bit.
+
+    The GT rows are replicated; `col_offset` is the global index of the shard's first anchor (`shard_bounds`).  Per-anchor
+    max / argmax over the GTs is local.  The per-GT max over ALL anchors — the low-quality step needs it
+    (`overlaps[i, :] == gt_max_overlaps[i]`, :200-207) — is ONE `all_reduce(MAX)` of k packed int64 keys (512 bytes for 64
+    GTs); the (k, n) matrix is neither gathered nor materialised.  `ignore_mask`: this shard's slice of the columns the
+    reference sets to -1 (:115-126).  Returns (assigned_gt_inds, max_overlaps, assigned_labels | None) of the shard;
+    `gt_argmax_overlaps` are global column indices inside the keys (`unpack_assign_keys`).
+
+    `op`: 'standard' | 'efficient' (the HIP kernels), or an object with the same `reduce` / `finalize` pair (the gloo
+    tests inject a CPU operator: the product's own is HIP-only by design)."""
+    if isinstance(neg_iou_thr, (tuple, list)):
+        neg_lo, neg_hi = float(neg_iou_thr[0]), float(neg_iou_thr[1])
+    else:
+        neg_lo, neg_hi = 0.0, float(neg_iou_thr)
+    fn = _HipAssignOp(op) if isinstance(op, str) else op
+    keys, ctx = fn.reduce(gt_bboxes, anchors_shard, col_offset, ignore_mask)
+    world, _rank = _world(group)
+    if world > 1:
+        dist.all_reduce(keys, op=dist.ReduceOp.MAX, group=group)   # stream-ordered on RCCL: no host synchronisation
+    return fn.finalize(ctx, keys, gt_labels, pos_iou_thr, neg_lo, neg_hi, min_pos_iou, match_low_quality, gt_max_assign_all)

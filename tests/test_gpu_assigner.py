@@ -248,3 +248,21 @@ def test_fused_two_shards_with_key_exchange_equal_one_device(A):
         gi.append(a); mo.append(m)
         assert torch.equal(gm, exw['gt_max_overlaps']) and torch.equal(gam, exw['gt_argmax_overlaps'])
     assert torch.equal(torch.cat(gi), whole.gt_inds) and torch.equal(torch.cat(mo), whole.max_overlaps)
+
+
+def test_sharded_assign_hip_operator_and_key_format(A):
+    """parallel.sharded_assign with the HIP operator (one rank: no collective) equals the fused call, and the keys the reduce
+    half hands to the all-reduce are exactly parallel.pack_assign_keys(gt_max, gt_argmax) — the format the gloo tests exercise."""
+    from sph_retina_amd import parallel as P
+    gt, boxes, labels = _scene(40, 3000, 5, 78)
+    kw = dict(pos_iou_thr=0.5, neg_iou_thr=(0.05, 0.4), min_pos_iou=0.1)
+    whole, ex = A.fused_assign(gt, boxes, labels, 'efficient', return_extras=True, **kw)
+    gi, mo, lab = P.sharded_assign(gt, boxes, 0, labels, op='efficient', **kw)
+    assert torch.equal(gi, whole.gt_inds) and torch.equal(mo, whole.max_overlaps) and torch.equal(lab, whole.labels)
+    op = P._HipAssignOp('efficient')
+    keys, _ctx = op.reduce(gt, boxes[1000:].contiguous(), 1000)
+    ov = A.fused_assign(gt, boxes[1000:].contiguous(), None, 'efficient', return_overlaps=True, **kw)[1]
+    mx, am = ov.max(dim=1)
+    assert torch.equal(keys, P.pack_assign_keys(mx, am + 1000))
+    v, i = P.unpack_assign_keys(keys)
+    assert torch.equal(v, mx) and torch.equal(i, am + 1000)
