@@ -37,6 +37,16 @@ Extra objects on the JSON line:
                 8 M-pair launch (288 MB).
   two_streams   N = 1: the same steps issued alternately on two HIP streams (independent launches: the ramp-up of one
                 overlaps the tail of the other); a side figure, never `value`.
+                `frac` divides by the event-timed launch (`kernel_ms`); `frac_step` by the driver-visible `ms_per_step`;
+                `frac_rocprof` by the committed rocprofv3 average (`rocprof_traced_kernel_ms`) — all three on the line so
+                that no reader has to recompute them.
+  parity        N = 1: the second half of BASELINE.json's metric ("...; max |dIoU|"), computed OUTSIDE the timed region on
+                the very boxes of this run (what the reference's own harness prints, tests/test_all_ious.py:61-78): max /
+                mean / p99.9 / count > 1e-5 / count > 1e-4 of |IoU_hip - IoU_ref| against ref32 (the C oracle in the
+                reference's fp32 operation order with mmcv's planar algorithm) and against f64 (the same algorithm in
+                double with an exact clip), for the benched arithmetic AND for the reference-order mode (with its time per
+                launch, so that the trade is on one line), next to ref32's own distance to f64 (the reference's noise
+                floor).  The oracle is the checker here, never the thing timed or shipped.
   cpu_baseline  the CPU oracle (C restatement of the reference path, "port") timed on this host's cores on a bounded
                 sample of the same workload, next to the reference's own Python timings.
 """
@@ -76,6 +86,7 @@ def parse_args(argv=None):
                     help="'fast' = default closed-form core ('robust' is an alias of it since round 2); 'reference' = the "
                          "reference's fp32 operation order")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true', help='skip the max |dIoU| block (oracle on the host, outside the timed region)')
     ap.add_argument('--gather', dest='gather', action='store_true', default=None,
                     help='N > 1: one RCCL all-gather of the per-shard IoU vectors per step, pipelined one step deep (default)')
     ap.add_argument('--no-gather', dest='gather', action='store_false', help='N > 1: time the sharded step only')
@@ -162,6 +173,30 @@ def cpu_baseline(n_sample=1_000_000):
                                  'source': 'BASELINE.md §3 (measured in the build container, not on this host)'}}
 
 
+def err_stats(got, want):
+    import numpy as np
+    d = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    d = d[np.isfinite(d)]
+    return {'max': float(d.max()), 'mean': float(d.mean()), 'p99_9': float(np.quantile(d, 0.999)),
+            'n_gt_1e-5': int((d > 1e-5).sum()), 'n_gt_1e-4': int((d > 1e-4).sum())}
+
+
+def parity_block(h1, h2, results, variant):
+    """max |dIoU| and friends of every (name -> IoU vector computed on the GPU from h1, h2) in `results` against the
+    oracle's two instantiations.  Runs on the host after the timed region."""
+    import numpy as np
+    from oracle import oracle as O
+    cores = min(O.max_threads(), len(os.sched_getaffinity(0)))
+    ref32 = O.iou_aligned(h1, h2, variant=variant, planar='mmcv', nthreads=cores)
+    f64 = O.iou_aligned(h1, h2, variant=variant, planar='exact', dtype=np.float64, nthreads=cores)
+    out = {'pairs': int(len(h1)), 'tolerance_north_star': 1e-5,
+           'ref32': 'C oracle, reference fp32 operation order, mmcv planar algorithm', 'f64': 'same algorithm in double, exact clip',
+           'ref32_vs_f64': err_stats(ref32, f64)}
+    for name, (iou, extra) in results.items():
+        out[name] = dict(extra, vs_ref32=err_stats(iou, ref32), vs_f64=err_stats(iou, f64))
+    return out
+
+
 def pmc_summary(pairs, variant, arithmetic, kernel):
     """This round's committed PMC summary (profiles/pmc_summary.json), ONLY when it was collected for this very
     configuration: a figure measured for another batch size / variant / build is not this run's measurement."""
@@ -201,7 +236,7 @@ def main(argv=None):
     if not dry:
         if rank == 0:
             _lib.build()   # no-op when sph_retina_amd/lib/libsph2pob_hip.so is up to date
-            if not args.no_cpu_baseline and world == 1:
+            if not (args.no_cpu_baseline and args.no_parity) and world == 1:
                 # the CPU-baseline leg's checker is built here, BEFORE this process initialises the GPU: on this pool a
                 # process must not fork + exec (make / gcc) once it has touched the device
                 from oracle import oracle as _O
@@ -307,9 +342,10 @@ def main(argv=None):
         el = timed(args.steps, False)
         no_gather = {'ms_per_step': el / args.steps * 1e3, 'value': total * args.steps / el}
     checksum = float(shards[0].double().sum().item())
+    iou_benched = shards[0].clone() if (world == 1 and not dry and not args.no_parity) else None
 
     # ---- side measurements on rank 0 (the other ranks wait at the final barrier) ----
-    kernel_ms = cold = at_8m = one_gpu_ms = two_streams = None
+    kernel_ms = cold = at_8m = one_gpu_ms = two_streams = parity_gpu = None
     if not dry:
         def events_ms(fn, reps):
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -365,6 +401,21 @@ def main(argv=None):
             if world > 1 and total == m8:
                 one_gpu_ms = t
             del c1, c2, co
+        if iou_benched is not None:
+            # the reference-order mode on the same boxes: its IoUs and its time per launch (the other side of the trade)
+            ref_c = (variant_c & 0xff) | G.FLAG_REFERENCE_ORDER
+            ref_out = torch.empty(n, dtype=torch.float32, device=dev)
+
+            def ref_kernel(r):
+                rc = lib.sph2pob_iou_aligned_f32(G.ptr(b1), G.ptr(b2), G.ptr(ref_out), ctypes.c_int64(n), 4, ref_c, 0, 0, 0,
+                                                 ctypes.c_void_p(stream.cuda_stream))
+                if rc:
+                    _lib.check(rc, 'sph2pob_iou_aligned_f32 (reference order)')
+            events_ms(ref_kernel, 100)
+            ref_ms = median_ms(ref_kernel, 100, 3)
+            parity_gpu = {args.arithmetic if args.arithmetic != 'robust' else 'fast': (iou_benched.cpu().numpy(), {'kernel_ms': kernel_ms, 'benched': True})}
+            if args.arithmetic != 'reference':
+                parity_gpu['reference_order'] = (ref_out.cpu().numpy(), {'kernel_ms': ref_ms, 'benched': False})
         if rank == 0 and world > 1 and one_gpu_ms is None and scaling == 'strong':
             c1, c2, co = make_boxes(total, 200, dev), make_boxes(total, 201, dev), torch.empty(total, dtype=torch.float32, device=dev)
             events_ms(lambda r: kernel(c1, c2, co, total), 100)
@@ -411,7 +462,10 @@ def main(argv=None):
                                # kernel 1-1.5 us per launch; bench.py itself reports as much when it is run under the tracer
                                'rocprof_traced_kernel_ms': (pmc.get('avg_ns') or 0) / 1e6 or None,
                                'kernel': kern, 'kernel_ms': kernel_ms, 'pairs_per_launch': n,
-                               'algorithmic_bytes_per_launch': BYTES_PER_PAIR * n}
+                               'algorithmic_bytes_per_launch': BYTES_PER_PAIR * n,
+                               # the same bytes over the driver-visible step and over the committed rocprofv3 average
+                               'frac_step': BYTES_PER_PAIR * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if world == 1 else None,
+                               'frac_rocprof': (BYTES_PER_PAIR * n / (pmc['avg_ns'] * 1e-9) / 1e9 / HBM_PEAK_GBS) if pmc.get('avg_ns') else None}
             if cold:
                 out['roofline']['cold'] = cold
             if at_8m:
@@ -430,6 +484,8 @@ def main(argv=None):
                 if no_gather:
                     ss['speedup_no_gather'] = one_gpu_ms / no_gather['ms_per_step']
             out['strong_scaling'] = ss
+        if parity_gpu is not None:
+            out['parity'] = parity_block(b1.cpu().numpy(), b2.cpu().numpy(), parity_gpu, args.variant)
         if not args.no_cpu_baseline and not dry and world == 1:   # rank 0 at N = 1 only
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

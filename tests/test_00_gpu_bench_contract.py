@@ -57,6 +57,21 @@ def test_bench_single_process_contract():
     assert d['config']['total_pairs'] == 1_000_000 and d['config']['gather'] is False
     if d['roofline']['traffic'] is not None:
         assert 'profiles/' in d['roofline']['traffic_source']
+    # round 3: the whole metric on the line — max |dIoU| of this run's own boxes, both arithmetics, and the three fractions
+    r = d['roofline']
+    assert abs(r['frac_step'] - 36e6 / (d['ms_per_step'] * 1e-3) / 8e12) < 1e-9
+    if r['rocprof_traced_kernel_ms']:
+        assert abs(r['frac_rocprof'] - 36e6 / (r['rocprof_traced_kernel_ms'] * 1e-3) / 8e12) < 1e-9
+    p = d['parity']
+    assert p['pairs'] == 1_000_000 and p['fast']['benched'] is True and p['reference_order']['benched'] is False
+    for arm in ('fast', 'reference_order'):
+        for ref in ('vs_ref32', 'vs_f64'):
+            st = p[arm][ref]
+            assert set(st) == {'max', 'mean', 'p99_9', 'n_gt_1e-5', 'n_gt_1e-4'}
+            # the benchmark distribution: a handful of pairs per million beyond 1e-5, none beyond 1e-4
+            assert st['mean'] < 1e-6 and st['p99_9'] < 1e-5 and st['n_gt_1e-5'] <= 25 and st['n_gt_1e-4'] == 0 and st['max'] < 1e-4
+    assert p['ref32_vs_f64']['n_gt_1e-5'] <= 25
+    assert p['reference_order']['kernel_ms'] > p['fast']['kernel_ms']
 
 
 def test_bench_under_torch_distributed_run_one_rank():

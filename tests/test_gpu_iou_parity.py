@@ -342,9 +342,57 @@ def test_full_size_properties_8m_and_sharded_assembly(S, oracle):
     # ragged shards (3 ranks) too
     assert torch.equal(torch.cat([S.sph2pob_standard_iou(b1[lo:hi], b2[lo:hi], is_aligned=True)
                                   for lo, hi in (shard_bounds(n, 3, r) for r in range(3))]), iou)
-    # a FIXED sample (every 160th pair): an unseeded random one met one of the batch's few jitter-threshold flips (1.3e-4,
-    # a handful among 8 M pairs: DESIGN.md §3) about once in a hundred runs
-    idx = torch.arange(0, n, 160, device='cuda')
-    ref = oracle.iou_aligned(b1[idx].cpu().numpy(), b2[idx].cpu().numpy(), variant='standard', planar='mmcv', nthreads=64)
-    d = np.abs(iou[idx].cpu().numpy() - ref)
-    assert d.mean() < 1e-7 and (d > 1e-5).sum() <= 5 and d.max() < 1e-4
+    # The WHOLE population against both oracles with fixed counts (round-2 VERDICT weak #3: a sample that misses the batch's
+    # few outliers is not a gate).  Measured on MI355X (tools/parity_population.py, profiles/r05g_parity_population.log), in
+    # brackets; bounds = those + ~30 %:   vs ref32: 178 pairs > 1e-5, 5 > 1e-4;   vs f64: 38 > 1e-5, NONE > 1e-4 (max 7.7e-5);
+    # the reference's own fp32 arithmetic vs f64: 145 / 5.  The five pairs beyond 1e-4 of ref32 are 211681, 2706828, 2876822,
+    # 2991369, 4712741, and on every one of them it is ref32 that is off, not the kernel (|kernel - f64| < 2e-6 on all five):
+    #   211681, 2706828, 4712741  mmcv's hull with absolute tolerances loses a vertex of a thin / large intersection
+    #                             (ref32 0.0129 for a true 0.0360; the reference-order kernel, whose planar stage is exact,
+    #                             agrees with f64 there too) — the planar stage's deliberate difference, DESIGN §3;
+    #   2876822, 2991369          fp32 conditioning of the reference's acos(clamp(dot)) form at |a_g - a_p| ~ 2 pi resp. at a
+    #                             centre distance of 0.017 rad: the reference-order kernel reproduces ref32 to 2e-7, the
+    #                             closed form reproduces f64.
+    # None is a jitter-threshold flip (the planar angle differences are nowhere near 1.2345678e-3).
+    h1, h2 = b1.cpu().numpy(), b2.cpu().numpy()
+    got = iou.cpu().numpy()
+    ref = oracle.iou_aligned(h1, h2, variant='standard', planar='mmcv', nthreads=64)
+    tru = oracle.iou_aligned(h1, h2, variant='standard', planar='exact', dtype=np.float64, nthreads=64)
+    r, t = err_stats(got, ref), err_stats(got, tru)
+    assert r['mean'] < 1e-7 and r['n5'] <= 230 and r['n4'] <= 8, r
+    assert t['mean'] < 5e-8 and t['n5'] <= 55 and t['n4'] == 0 and t['max'] < 1e-4, t
+    far = np.abs(got - ref) > 1e-4
+    assert (np.abs(ref[far] - tru[far]) > 1e-4).all()       # wherever the kernel leaves ref32 by 1e-4, ref32 has left f64
+
+
+@pytest.mark.parametrize('variant,n5_ref,n4_ref', [('standard', 700, 12), ('efficient', 200, 9)])
+def test_full_size_assigner_matrix_25m_whole_population(S, oracle, variant, n5_ref, n4_ref):
+    """All 25 141 248 pairs of the 64 GT x 392 832-anchor matrix (the literal 1024 x 2048 grid of configs[3]) against both
+    oracles (round 2 checked every 97th column).  Measured (profiles/r05g_parity_population.log): standard 562 pairs > 1e-5 and
+    8 > 1e-4 against ref32, 13 and 0 against f64 (max 2.3e-5); efficient 153 / 6 and 13 / 0.  As for the 8 M batch, the pairs
+    beyond 1e-4 of ref32 — (GT, anchor) = (19, 362045), (23, 376178), (37, 312992), (39, 266155), (40, 12646), (40, 243303),
+    (44, 322598), (59, 232336) for `standard` — are all pairs on which ref32 is > 1e-4 from f64 and the kernel is within 1e-6
+    of f64: five are slivers / thin intersections that mmcv's tolerance hull drops or truncates (ref32 2e-6 for a true
+    7.8e-3), three are the reference's fp32 conditioning at centre distances below 0.14 rad."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from bench_configs import retina_anchors
+    S.set_arithmetic('fast')
+    anchors = retina_anchors(1024, 2048)
+    g = torch.Generator().manual_seed(0)
+    u = torch.rand((64, 4), generator=g)
+    gt = torch.stack([u[:, 0] * 360, 20 + u[:, 1] * 140, 5 + u[:, 2] * 85, 5 + u[:, 3] * 85], 1)
+    fn = S.sph2pob_standard_iou if variant == 'standard' else S.sph2pob_efficient_iou
+    ov = fn(gt.cuda(), anchors).cpu().numpy()
+    a = anchors.cpu().numpy()
+    ref = oracle.iou_pairwise(gt.numpy(), a, variant=variant, planar='mmcv', nthreads=64)
+    tru = oracle.iou_pairwise(gt.numpy(), a, variant=variant, planar='exact', dtype=np.float64, nthreads=64)
+    r, t = err_stats(ov.ravel(), ref.ravel()), err_stats(ov.ravel(), tru.ravel())
+    assert r['mean'] < 2e-8 and r['n5'] <= n5_ref and r['n4'] <= n4_ref, r
+    assert t['mean'] < 5e-9 and t['n5'] <= 25 and t['n4'] == 0 and t['max'] < 5e-5, t
+    far = np.abs(ov - ref) > 1e-4
+    assert (np.abs(ref[far] - tru[far]) > 1e-4).all()
+    # exact zeros: the cull and mmcv's hull disagree only on slivers
+    dis = (ov == 0) != (ref == 0)
+    assert dis.sum() < 3000 and max(float(ov[dis].max()), float(ref[dis].max())) < 1e-2
