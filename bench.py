@@ -189,11 +189,14 @@ def parity_block(h1, h2, results, variant):
     cores = min(O.max_threads(), len(os.sched_getaffinity(0)))
     ref32 = O.iou_aligned(h1, h2, variant=variant, planar='mmcv', nthreads=cores)
     f64 = O.iou_aligned(h1, h2, variant=variant, planar='exact', dtype=np.float64, nthreads=cores)
+    ref32d = O.iou_aligned(h1, h2, variant=variant, planar='diff', nthreads=cores)
     out = {'pairs': int(len(h1)), 'tolerance_north_star': 1e-5,
-           'ref32': 'C oracle, reference fp32 operation order, mmcv planar algorithm', 'f64': 'same algorithm in double, exact clip',
-           'ref32_vs_f64': err_stats(ref32, f64)}
+           'ref32': 'C oracle, reference fp32 operation order, mmcv box_iou_rotated planar algorithm (restated: mmcv is absent)',
+           'ref32_diff': "the same with the reference's vendored planar IoU (sphdet/iou/diff_iou_rotated.py: pinned by fixtures)",
+           'f64': 'same algorithm in double, exact clip',
+           'ref32_vs_f64': err_stats(ref32, f64), 'ref32_diff_vs_f64': err_stats(ref32d, f64)}
     for name, (iou, extra) in results.items():
-        out[name] = dict(extra, vs_ref32=err_stats(iou, ref32), vs_f64=err_stats(iou, f64))
+        out[name] = dict(extra, vs_ref32=err_stats(iou, ref32), vs_ref32_diff=err_stats(iou, ref32d), vs_f64=err_stats(iou, f64))
     return out
 
 

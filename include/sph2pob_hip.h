@@ -216,6 +216,22 @@ int sph2pob_nms_segmented_f32(const float* boxes_sorted, const int64_t* cls_sort
                               void* stream);
 
 /*
+ * sph_batched_nms without the host (sphdet/bbox/nms/sph_nms.py:22-60): UNSORTED boxes (k, box_dim), scores (k), class ids
+ * idxs (k, int64; NULL = one class: sph_nms_op, :62-74) -> the kept boxes' original indices in descending-score order
+ * (ties by ascending index), at most max_num of them, and dets = (box, score) rows of box_dim + 1 floats.  Four launches,
+ * no host work: a one-workgroup bitonic sort of composite (class | -score | index) keys in LDS, the suppression matrix,
+ * the per-class sweeps, and a one-workgroup sort of the kept boxes by score.  *status (device int) = number of rows written
+ * to keep / dets, or -1 when a class id is outside [0, 262 143] (nothing valid was written: use the sorted-input entry
+ * points).  k <= sph2pob_batched_nms_max_boxes() (16 384), any number per class.  keep / dets must hold min(max_num, k) rows;
+ * workspace: sph2pob_batched_nms_workspace_bytes(k, box_dim) bytes, no initialisation.
+ */
+int sph2pob_batched_nms_max_boxes(void);
+int64_t sph2pob_batched_nms_workspace_bytes(int64_t k, int box_dim);
+int sph2pob_batched_nms_f32(const float* boxes, const float* scores, const int64_t* idxs, int64_t k, int box_dim, int variant,
+                            float iou_threshold, int64_t max_num, void* workspace, int64_t* keep, float* dets, int* status,
+                            void* stream);
+
+/*
  * MaxIoUAssigner epilogue on a (k, n) overlaps matrix (rows = GT, columns = boxes), SURVEY §8f-1.
  * Replaces assign_wrt_overlaps (mmdet/core/bbox/assigners/max_iou_assigner.py:135-220) for k > 0, n > 0:
  *   max_overlaps, argmax_overlaps       = overlaps.max(dim=0)   (:171)   first maximal index on ties

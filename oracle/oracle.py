@@ -222,7 +222,7 @@ def transform_vjp_fd(b1, b2, g1, g2, variant='standard', edge='arc', jitter=True
     return out
 
 
-def nms_op(boxes, scores, iou_threshold, variant='efficient', planar='mmcv'):
+def nms_op(boxes, scores, iou_threshold, variant='efficient', planar='mmcv', nthreads=1):
     """sph_nms_op: sphdet/bbox/nms/sph_nms.py:62-74.  Stable descending sort (ties keep input order)."""
     boxes = _np(boxes, np.float32)
     order = np.argsort(-np.asarray(scores, dtype=np.float32), kind='stable')
@@ -236,7 +236,7 @@ def nms_op(boxes, scores, iou_threshold, variant='efficient', planar='mmcv'):
         elif variant == 'naive':
             iou = naive_iou(boxes[order[:1]], boxes[order[1:]], is_aligned=False, planar=planar).reshape(-1)
         else:
-            iou = iou_pairwise(boxes[order[:1]], boxes[order[1:]], variant=variant, planar=planar).reshape(-1)
+            iou = iou_pairwise(boxes[order[:1]], boxes[order[1:]], variant=variant, planar=planar, nthreads=nthreads).reshape(-1)
         order = order[1:][iou <= np.float32(iou_threshold)]
     return np.asarray(keep, dtype=np.int64)
 

@@ -1,8 +1,11 @@
 """ctypes binding of libsph2pob_hip.so (the C ABI declared in include/sph2pob_hip.h).
 
-There is no CPU fallback and no torch extension: if the shared library is missing or a symbol is absent the
-import of the product fails loudly.  ``build()`` cross-compiles the library for gfx950 with hipcc (works
-without a GPU); the built .so lives in-tree under sph_retina_amd/lib/ so it travels with the source tree.
+No torch extension and no silent fallback: if a shared library is missing or a symbol is absent the product fails
+loudly.  ``build()`` cross-compiles libsph2pob_hip.so for gfx950 with hipcc (works without a GPU) and compiles
+libsph2pob_host.so — the CPU twins (`*_cpu`) of the same entry points, the product's own __host__ __device__ arithmetic
+instantiated for the host (csrc/sph2pob_host.hip) — with the same compiler; both live in-tree under
+sph_retina_amd/lib/ so they travel with the source tree.  CPU tensors are served by the host library, device tensors by
+the HIP one; neither ever touches oracle/.
 """
 import ctypes
 import os
@@ -13,7 +16,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_DIR = os.path.join(_HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libsph2pob_hip.so')
+HOST_LIB_PATH = os.path.join(LIB_DIR, 'libsph2pob_host.so')
 SOURCES = ['sph2pob_kernels.hip', 'sph2pob_coder.hip']
+HOST_SOURCES = ['sph2pob_host.hip']
+HOST_FLAGS = ['--offload-arch=gfx950', '--cuda-host-only', '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-pthread']
+# the entry points that have a CPU twin `<name>_cpu` with the same signature (the stream argument is ignored)
+HOST_TWINS = ['sph2pob_iou_aligned_f32', 'sph2pob_iou_pairwise_f32', 'sph2pob_planar_iou_f32', 'sph2pob_transform_f32',
+              'sph2pob_transform_bwd_f32', 'sph2pob_transform_bwd_general_f32', 'sph2pob_loss_fwd_f32', 'sph2pob_loss_bwd_f32',
+              'sph2pob_loss_fwd_sum_f32', 'sph2pob_loss_fwd_grad_f32', 'sph2pob_loss_grad_scale_f32', 'sph2pob_sum_f32',
+              'sph2pob_nms_segmented_f32', 'sph2pob_nms_f32', 'sph2pob_assign_f32']
 HEADERS = ['sph2pob_device.hpp', 'sph2pob_loss.hpp', 'sph2pob_fast.hpp', 'sph2pob_unbiased.hpp', os.path.join('..', '..', 'include', 'sph2pob_hip.h')]
 # -fno-slp-vectorize: hipcc otherwise pairs scalar fp32 mul/add into v_pk_* (+ v_mov shuffles); packed fp32 issues at
 # half the rate of plain VALU on gfx950 (tools/ubench/valu_rate2.hip), measured 12 % slower on the dominant kernel
@@ -73,6 +84,9 @@ SIGNATURES = {
     'sph2pob_nms_segmented_workspace_bytes': [_i64, _i64],
     'sph2pob_nms_segmented_f32': [_c_f32p, ctypes.c_void_p, _i64, _int, _int, ctypes.c_float, _i64, ctypes.c_void_p,
                                   ctypes.c_void_p, ctypes.c_void_p],
+    'sph2pob_batched_nms_max_boxes': [],
+    'sph2pob_batched_nms_workspace_bytes': [_i64, _int],
+    'sph2pob_batched_nms_f32': [_c_f32p, _c_f32p, ctypes.c_void_p, _i64, _int, _int, ctypes.c_float, _i64] + [ctypes.c_void_p] * 5,
     'sph2pob_coder_encode_f32': [_c_f32p, _c_f32p, ctypes.c_void_p, ctypes.c_void_p, _c_f32p, _i64, _int,
                                  ctypes.c_void_p],
     'sph2pob_coder_decode_f32': [_c_f32p, _c_f32p, ctypes.c_void_p, ctypes.c_void_p, _c_f32p, _i64, _int, _int,
@@ -85,7 +99,8 @@ SIGNATURES = {
 }
 _RESTYPES = {'sph2pob_loss_sum_workspace_floats': ctypes.c_int64, 'sph2pob_target_arch': ctypes.c_char_p, 'sph2pob_error_string': ctypes.c_char_p,
              'sph2pob_nms_workspace_bytes': ctypes.c_int64, 'sph2pob_nms_segmented_workspace_bytes': ctypes.c_int64, 'sph2pob_assign_workspace_bytes': ctypes.c_int64,
-             'sph2pob_iou_assign_workspace_bytes': ctypes.c_int64, 'sph2pob_iou_assign_state_bytes': ctypes.c_int64}
+             'sph2pob_iou_assign_workspace_bytes': ctypes.c_int64, 'sph2pob_iou_assign_state_bytes': ctypes.c_int64,
+             'sph2pob_batched_nms_workspace_bytes': ctypes.c_int64}
 
 ABI_VERSION = 1
 
@@ -94,32 +109,42 @@ class Sph2PobLibraryError(RuntimeError):
     pass
 
 
-def _stale():
-    if not os.path.exists(LIB_PATH):
+def _older_than(path, sources):
+    if not os.path.exists(path):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    t = os.path.getmtime(path)
+    deps = [os.path.join(CSRC, s) for s in sources] + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 ... -> sph_retina_amd/lib/libsph2pob_hip.so (no GPU needed)."""
-    if not force and not _stale():
-        return LIB_PATH
+def _stale():
+    return _older_than(LIB_PATH, SOURCES) or _older_than(HOST_LIB_PATH, HOST_SOURCES)
+
+
+def _compile(flags, sources, out, verbose):
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
-        raise Sph2PobLibraryError('hipcc not found: cannot build libsph2pob_hip.so')
+        raise Sph2PobLibraryError(f'hipcc not found: cannot build {os.path.basename(out)}')
     os.makedirs(LIB_DIR, exist_ok=True)
-    tmp = f'{LIB_PATH}.tmp.{os.getpid()}'   # built aside and renamed: other ranks / processes never see a partial file
-    cmd = [hipcc] + HIPCC_FLAGS + ['-o', tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+    tmp = f'{out}.tmp.{os.getpid()}'   # built aside and renamed: other ranks / processes never see a partial file
+    cmd = [hipcc] + flags + ['-o', tmp] + [os.path.join(CSRC, s) for s in sources]
     if verbose:
         print(' '.join(cmd))
     try:
         subprocess.check_call(cmd, cwd=CSRC)
-        os.replace(tmp, LIB_PATH)
+        os.replace(tmp, out)
     finally:
         if os.path.exists(tmp):
             os.remove(tmp)
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 ... -> sph_retina_amd/lib/libsph2pob_hip.so (no GPU needed) and the host twins
+    -> sph_retina_amd/lib/libsph2pob_host.so."""
+    if force or _older_than(LIB_PATH, SOURCES):
+        _compile(HIPCC_FLAGS, SOURCES, LIB_PATH, verbose)
+    if force or _older_than(HOST_LIB_PATH, HOST_SOURCES):
+        _compile(HOST_FLAGS, HOST_SOURCES, HOST_LIB_PATH, verbose)
     return LIB_PATH
 
 
@@ -150,6 +175,34 @@ def lib():
         raise Sph2PobLibraryError('libsph2pob_hip.so ABI version mismatch: rebuild the library')
     _LIB = handle
     return _LIB
+
+
+_HOST = None
+
+
+def host_lib():
+    """libsph2pob_host.so with typed `<name>_cpu` entry points (the CPU twins); raises Sph2PobLibraryError when unusable."""
+    global _HOST
+    if _HOST is not None:
+        return _HOST
+    if not os.path.exists(HOST_LIB_PATH):
+        raise Sph2PobLibraryError(
+            f'{HOST_LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"`.  CPU tensors '
+            'are served by this library only (there is no eager / oracle fallback).')
+    try:
+        handle = ctypes.CDLL(HOST_LIB_PATH)
+    except OSError as e:
+        raise Sph2PobLibraryError(f'cannot load {HOST_LIB_PATH}: {e}') from e
+    for name in HOST_TWINS:
+        try:
+            fn = getattr(handle, name + '_cpu')
+        except AttributeError as e:
+            raise Sph2PobLibraryError(f'{HOST_LIB_PATH} does not export {name}_cpu') from e
+        fn.argtypes = SIGNATURES[name]
+        fn.restype = _int
+    handle.sph2pob_host_threads.restype = _int
+    _HOST = handle
+    return _HOST
 
 
 def check(rc, what):

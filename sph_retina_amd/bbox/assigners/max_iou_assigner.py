@@ -11,7 +11,8 @@ With a closed-form Sph2Pob calculator (`sph2pob_standard_iou` / `sph2pob_efficie
 one step further and never materialises the (k, n) overlaps (`sph2pob_iou_assign_f32`): the pairwise kernel keeps the
 per-anchor and per-GT maxima while it finishes the pairs, and the low-quality step re-evaluates a GT row only against the
 column tile that holds its maximum.  Bit-identical to the matrix route (tests/test_gpu_assigner.py).
-Not supported (raises): `gpu_assign_thr` CPU off-loading (there is no CPU path).
+`gpu_assign_thr` (:100-110, :128-133) moves an assignment with more GTs than the threshold to the CPU, as the reference does —
+served there by the product's host twins (libsph2pob_host.so) — and returns the result on the boxes' device.
 """
 import ctypes
 
@@ -88,7 +89,7 @@ def assign_wrt_overlaps(overlaps, gt_labels=None, pos_iou_thr=0.5, neg_iou_thr=0
     if gt_labels is not None:
         gl = gt_labels.to(device=dev, dtype=torch.int64).contiguous()
         labels = torch.empty((num_bboxes,), dtype=torch.int64, device=dev)
-    ws = torch.empty((_lib.lib().sph2pob_assign_workspace_bytes(num_gts, num_bboxes) // 8,), dtype=torch.int64, device=dev)
+    ws = torch.empty((_lib.lib().sph2pob_assign_workspace_bytes(num_gts, num_bboxes) // 8 if dev.type != 'cpu' else 1,), dtype=torch.int64, device=dev)
     G.call('sph2pob_assign_f32', dev, G.ptr(ov), ctypes.c_int64(num_gts), ctypes.c_int64(num_bboxes),
            ctypes.c_float(pos_iou_thr), ctypes.c_float(neg_lo), ctypes.c_float(neg_hi), ctypes.c_float(min_pos_iou),
            int(bool(match_low_quality)), int(bool(gt_max_assign_all)), G.ptr(gl), G.ptr(max_ov), G.ptr(argmax_ov),
@@ -116,6 +117,8 @@ def fused_assign(gt_bboxes, bboxes, gt_labels=None, variant='standard', pos_iou_
     without the (k, n) matrix (`return_overlaps=True` also writes it).  `ignore_mask`: optional (n,) bool, the columns the
     reference sets to -1 (:115-126).  k > 0 and n > 0; boxes (k, 4|5) / (n, 4|5) on the MI355X."""
     G.require_hip(gt_bboxes, bboxes)
+    if not bboxes.is_cuda:
+        raise RuntimeError('fused_assign runs on MI355X tensors (on the CPU: iou_calculator + assign_wrt_overlaps)')
     gt, bx = G.as_f32_nograd(gt_bboxes), G.as_f32_nograd(bboxes)
     k, n, dim = gt.size(0), bx.size(0), gt.size(1)
     assert bx.size(1) == dim and dim in (4, 5) and k > 0 and n > 0
@@ -174,8 +177,14 @@ class SphMaxIoUAssigner:
         self.iou_calculator = build_iou_calculator(iou_calculator) if isinstance(iou_calculator, dict) else iou_calculator
 
     def assign(self, bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None):
-        if self.gpu_assign_thr > 0 and gt_bboxes.shape[0] > self.gpu_assign_thr:
-            raise NotImplementedError('gpu_assign_thr (CPU off-loading) is not available: the engine has no CPU path')
+        if self.gpu_assign_thr > 0 and gt_bboxes.shape[0] > self.gpu_assign_thr and bboxes.is_cuda:   # :100-110, :128-133
+            device = bboxes.device
+            res = self.assign(bboxes.cpu(), gt_bboxes.cpu(), None if gt_bboxes_ignore is None else gt_bboxes_ignore.cpu(),
+                              None if gt_labels is None else gt_labels.cpu())
+            res.gt_inds, res.max_overlaps = res.gt_inds.to(device), res.max_overlaps.to(device)
+            if res.labels is not None:
+                res.labels = res.labels.to(device)
+            return res
         ignore_mask = None
         if (self.ignore_iof_thr > 0 and gt_bboxes_ignore is not None and gt_bboxes_ignore.numel() > 0
                 and bboxes.numel() > 0):  # :115-126

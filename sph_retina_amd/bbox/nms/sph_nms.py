@@ -1,8 +1,10 @@
 """Spherical NMS — mirrors sphdet/bbox/nms/sph_nms.py:7-74 (SphNMS, sph_batched_nms, sph_nms_op).
 
 The reference loops in Python: per class, per kept box, one full Sph2Pob IoU pipeline (1 x K) and a host sync.
-Here all classes go through TWO kernels (`sph2pob_nms_f32`): the suppression bit-matrix with the Sph2Pob IoU
-evaluated once per same-class pair, and a single-wave greedy sweep.  Host work is sorting / gathering only.
+Here a call of up to 16 384 candidates is ONE launcher call and four kernels with no host work (`sph2pob_batched_nms_f32`:
+composite-key sort in LDS, suppression bit-matrix with the Sph2Pob IoU evaluated once per same-class pair, per-class greedy
+sweeps, score-ordered selection) and one host read — the number of kept boxes, which sizes the result.  Larger calls sort
+with torch and run the same two NMS kernels; a class of more than 32 704 boxes is swept in chunks.
 
 Kept behaviour: accepted calculator names, `iou <= thr` keeps, per-class suppression regardless of
 `class_agnostic` (the reference pops the flag but never uses it, :34,44), final ordering by descending score,
@@ -50,13 +52,17 @@ def _nms_sorted(boxes_sorted, cls_sorted, iou_threshold, variant):
     # host (one sync; the caller's nonzero() syncs anyway).  multiclass_nms hands over every (box, class) candidate
     # above score_thr — far more than 32 768 rows in total, but a class segment stays small.
     # Small inputs take the full k x k/64 layout (<= 8 MB) and skip that sync.
-    max_seg = k if cls_sorted is None or k <= 8192 else int(torch.unique_consecutive(cls_sorted, return_counts=True)[1].max())
+    max_seg = k if cls_sorted is None or k <= 8192 or dev.type == 'cpu' else int(torch.unique_consecutive(cls_sorted, return_counts=True)[1].max())
     limit = lib.sph2pob_nms_max_boxes()
+    if dev.type == 'cpu':   # the host twin keeps no suppression matrix: no workspace, no per-class limit
+        G.call('sph2pob_nms_segmented_f32', dev, G.ptr(boxes_sorted), G.ptr(cls_sorted), ctypes.c_int64(k), dim, G.VARIANTS[variant],
+               ctypes.c_float(iou_threshold), ctypes.c_int64(0), None, G.ptr(keep), None)
+        return keep
     if max_seg > limit:
         # the sweep keeps one class segment's "removed" bit-vector in LDS: 32 704 boxes per class; the
         # reference has no limit but needs one host round trip per kept box (minutes at this size)
-        raise ValueError(f'sph nms supports at most {limit} boxes per class segment, got {max_seg}; '
-                         'lower nms_pre / raise score_thr, or split the call by class')
+        raise ValueError(f'the sweep kernel takes at most {limit} boxes per class segment, got {max_seg}: callers route longer '
+                         'classes through _nms_one_class_chunked')
     ws = torch.empty((lib.sph2pob_nms_segmented_workspace_bytes(k, max_seg) // 8,), dtype=torch.int64, device=dev)
     G.call('sph2pob_nms_segmented_f32', dev, G.ptr(boxes_sorted), G.ptr(cls_sorted), ctypes.c_int64(k), dim,
            G.VARIANTS[variant], ctypes.c_float(iou_threshold), ctypes.c_int64(max_seg), G.ptr(ws), G.ptr(keep),
@@ -64,14 +70,77 @@ def _nms_sorted(boxes_sorted, cls_sorted, iou_threshold, variant):
     return keep
 
 
+def _fused_nms(boxes, scores, idxs, iou_threshold, max_num, variant):
+    """The host-free route (k <= 16 384) -> (dets, keep), or None when a class id does not fit the composite sort key."""
+    lib = _lib.lib()
+    k, dim = boxes.shape
+    dev = boxes.device
+    b, sc = G.as_f32_nograd(boxes), G.as_f32_nograd(scores)
+    ix = None if idxs is None else idxs.to(torch.int64).contiguous()
+    rows = max(min(int(max_num), k), 0)
+    need = lib.sph2pob_batched_nms_workspace_bytes(k, dim)
+    ws = G.scratch(dev, need + 256)                      # cached per (device, stream); its tail holds the status word
+    status = ws[need:need + 4].view(torch.int32)
+    keep = torch.empty((rows,), dtype=torch.int64, device=dev)
+    dets = torch.empty((rows, dim + 1), dtype=torch.float32, device=dev)
+    G.call('sph2pob_batched_nms_f32', dev, G.ptr(b), G.ptr(sc), G.ptr(ix), k, dim, G.VARIANTS[variant], float(iou_threshold), rows,
+           G.ptr(ws), G.ptr(keep), G.ptr(dets), G.ptr(status), G.raw_stream_of(dev))
+    n = int(status.item())   # the one host read: the result's length
+    if n < 0:
+        return None
+    dets = dets[:n]
+    if boxes.dtype != torch.float32 and boxes.is_floating_point():
+        dets = dets.to(boxes.dtype)
+    return dets, keep[:n]
+
+
+def _pairwise_fn(variant):
+    from ...iou import sph_iou_api as A
+    return {'efficient': A.sph2pob_efficient_iou, 'standard': A.sph2pob_standard_iou, 'unbiased': A.unbiased_iou,
+            'naive': A.naive_iou}[variant]
+
+
+def _nms_one_class_chunked(boxes_sorted, iou_threshold, variant, chunk=16384):
+    """Greedy NMS of ONE class of any length, boxes in descending-score order -> keep flags (bool).  Chunks of `chunk`
+    boxes: a chunk's boxes are first tested against every box kept so far (one pairwise IoU launch, rows = the kept boxes
+    in the bboxes1 role, as sph_nms_op has them, sph_nms.py:70), the survivors go through the NMS kernels.  The reference
+    has no size limit (one IoU pipeline + host sync per kept box: minutes at this size); the sweep kernel's limit is 32 704."""
+    n = boxes_sorted.size(0)
+    flags = torch.zeros((n,), dtype=torch.bool, device=boxes_sorted.device)
+    kept = None
+    iou = _pairwise_fn(variant)
+    for lo in range(0, n, chunk):
+        part = boxes_sorted[lo:lo + chunk]
+        alive = None
+        if kept is not None and kept.size(0) > 0:
+            alive = ~(iou(kept, part) > iou_threshold).any(dim=0)
+            part = part[alive]
+        if part.size(0) == 0:
+            continue
+        f = _nms_sorted(part.contiguous(), None, iou_threshold, variant).bool()
+        pos = torch.arange(lo, min(lo + chunk, n), device=flags.device)
+        if alive is not None:
+            pos = pos[alive]
+        flags[pos[f]] = True
+        kept = part[f] if kept is None else torch.cat([kept, part[f]])
+    return flags
+
+
 def sph_nms_op(boxes, scores, iou_threshold, iou_calculator='sph2pob_efficient'):
     """Single-class greedy NMS -> indices of kept boxes in descending-score order (reference :62-74)."""
     variant = _variant_of(iou_calculator)
     assert boxes.size(1) in [4, 5]
     G.require_hip(boxes, scores)
+    k = boxes.size(0)
+    if boxes.is_cuda and 0 < k <= _lib.lib().sph2pob_batched_nms_max_boxes():
+        return _fused_nms(boxes, scores, None, iou_threshold, k, variant)[1]
     order = torch.argsort(scores, descending=True, stable=True)
-    flags = _nms_sorted(G.as_f32(boxes[order]), None, float(iou_threshold), variant)
-    return order[flags.bool()]
+    bs = G.as_f32(boxes[order])
+    if boxes.is_cuda and k > _lib.lib().sph2pob_nms_max_boxes():
+        flags = _nms_one_class_chunked(bs, float(iou_threshold), variant)
+    else:
+        flags = _nms_sorted(bs, None, float(iou_threshold), variant).bool()
+    return order[flags]
 
 
 def sph_batched_nms(boxes, scores, idxs, nms_cfg, iou_calculator='efficient', class_agnostic=False):
@@ -86,11 +155,35 @@ def sph_batched_nms(boxes, scores, idxs, nms_cfg, iou_calculator='efficient', cl
     max_num = min(nms_cfg_.pop('max_num', boxes.shape[0]), boxes.shape[0])
     G.require_hip(boxes, scores, idxs)
     assert boxes.size(1) in [4, 5]
-    # sort by (class ascending, score descending): two stable sorts
+    variant = _variant_of(iou_calculator)
+    k = boxes.size(0)
+    lib = _lib.lib()
+    if boxes.is_cuda and 0 < k <= lib.sph2pob_batched_nms_max_boxes() and not idxs.is_floating_point():
+        out = _fused_nms(boxes, scores, idxs, iou_threshold, max_num, variant)
+        if out is not None:
+            return out
+    # the general route: sort by (class ascending, score descending) with two stable torch sorts
     by_score = torch.argsort(scores, descending=True, stable=True)
     order = by_score[torch.argsort(idxs[by_score], stable=True)]
-    flags = _nms_sorted(G.as_f32(boxes[order]), idxs[order].to(torch.int64).contiguous(), float(iou_threshold),
-                        _variant_of(iou_calculator))
+    cls_sorted = idxs[order].to(torch.int64).contiguous()
+    boxes_sorted = G.as_f32(boxes[order])
+    limit = lib.sph2pob_nms_max_boxes()
+    counts = torch.unique_consecutive(cls_sorted, return_counts=True)[1] if k > 8192 and boxes.is_cuda else None
+    if counts is not None and int(counts.max()) > limit:
+        # a class longer than the sweep's limit: that class in chunks, the others (as one call) through the kernels
+        bounds = torch.cumsum(counts, 0).tolist()
+        flags = torch.zeros((k,), dtype=torch.uint8, device=boxes.device)
+        small = torch.ones((k,), dtype=torch.bool, device=boxes.device)
+        lo = 0
+        for hi in bounds:
+            if hi - lo > limit:
+                flags[lo:hi] = _nms_one_class_chunked(boxes_sorted[lo:hi], float(iou_threshold), variant).to(torch.uint8)
+                small[lo:hi] = False
+            lo = hi
+        if bool(small.any()):
+            flags[small] = _nms_sorted(boxes_sorted[small].contiguous(), cls_sorted[small].contiguous(), float(iou_threshold), variant)
+    else:
+        flags = _nms_sorted(boxes_sorted, cls_sorted, float(iou_threshold), variant)
     # the reference takes the kept original indices in ascending order (:49) and sorts them by descending score (:50-51);
     # a stable sort breaks ties by that ascending index — which is the order `by_score` already has, so the kept entries
     # of `by_score` ARE that list: one scatter + one masked gather instead of nonzero + gather + a third sort

@@ -841,6 +841,39 @@ __global__ __launch_bounds__(kBlock) void sum_pass2(const float* __restrict__ ws
 // the rows in order; the greedy dependency inside a 64-row block is resolved on the 64x64 diagonal block held
 // one row per lane (readlane, scalar bit ops), then the kept rows of the block are OR-ed into the running
 // "removed" bit-vector (LDS) with lanes striding over the words, so global loads are never on the serial chain.
+// A row's class segment [begin, end) in the class-sorted order, found by the whole wave: 64 probes per round, both ends in
+// the same rounds — three dependent round trips for 5 000 rows where a per-lane binary search made 2 x 13 (the NMS kernels
+// of a 5 000-box call spent most of their ~12 us in those searches).  All lanes of the wave pass the same i.
+__device__ __forceinline__ void wave_class_segment(const int64_t* __restrict__ cls, int64_t k, int64_t i, int64_t& seg_begin, int64_t& seg_end,
+                                                   bool want_begin = true) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ci = cls[i];
+    // end: the first e in (i, k] with e == k or cls[e] > ci; invariant: cls[elo - 1] <= ci, answer in [elo, ehi]
+    // begin: the first b in [0, i] with cls[b] >= ci (== ci); invariant: answer in [blo, bhi], cls[bhi] >= ci
+    int64_t elo = i + 1, ehi = k, blo = 0, bhi = want_begin ? i : 0;
+    if (!want_begin) blo = 0;
+    while (elo < ehi || blo < bhi) {
+        const int64_t es = (ehi - elo + 63) / 64, bs = (bhi - blo + 63) / 64;
+        const int64_t ep = elo + lane * es, bp = blo + lane * bs;
+        const bool ein = elo < ehi && ep < ehi, bin = blo < bhi && bp < bhi;
+        const int64_t ce = cls[ein ? ep : i], cb = cls[bin ? bp : i];   // (two independent loads per round)
+        const int te = __popcll(__builtin_amdgcn_ballot_w64(ein && ce <= ci));   // probes still inside the class (monotone)
+        const int tb = __popcll(__builtin_amdgcn_ballot_w64(bin && cb < ci));    // probes still in front of it
+        if (elo < ehi) {
+            const int64_t base = elo;
+            if (te == 0) ehi = elo;
+            else { elo = base + (te - 1) * es + 1; const int64_t cap = base + te * es; ehi = cap < ehi ? cap : ehi; }
+        }
+        if (blo < bhi) {
+            const int64_t base = blo;
+            if (tb == 0) bhi = blo;
+            else { blo = base + (tb - 1) * bs + 1; const int64_t cap = base + tb * bs; bhi = cap < bhi ? cap : bhi; }
+        }
+    }
+    seg_end = elo;
+    seg_begin = want_begin ? blo : 0;
+}
+
 template <int VARIANT, int DIM, bool FAST>
 __global__ __launch_bounds__(kBlock) void nms_mask_kernel(const float* __restrict__ boxes,
                                                          const int64_t* __restrict__ cls, int64_t k, int words,
@@ -852,21 +885,7 @@ __global__ __launch_bounds__(kBlock) void nms_mask_kernel(const float* __restric
     const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + wave;
     if (i >= k) return;
     int64_t seg_begin = 0, seg_end = k;  // row i's class segment [seg_begin, seg_end) (boxes are sorted by class)
-    if (cls) {
-        const int64_t ci = cls[i];
-        int64_t lo = i + 1, hi = k;
-        while (lo < hi) {
-            int64_t mid = (lo + hi) >> 1;
-            if (cls[mid] <= ci) lo = mid + 1; else hi = mid;
-        }
-        seg_end = lo;
-        lo = 0; hi = i;
-        while (lo < hi) {
-            int64_t mid = (lo + hi) >> 1;
-            if (cls[mid] < ci) lo = mid + 1; else hi = mid;
-        }
-        seg_begin = lo;
-    }
+    if (cls) wave_class_segment(cls, k, i, seg_begin, seg_end);
     const int64_t base = seg_begin >> 6;
     // relative word range of the later columns; empty when seg_end == i + 1; clipped to the row (a caller that
     // under-states the largest segment gets truncated suppression, never an out-of-bounds store)
@@ -910,21 +929,7 @@ __global__ __launch_bounds__(kBlock) void nms_mask_compact_kernel(const float* _
     const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + wave;
     if (i >= k) return;   // whole waves leave: no workgroup barrier below
     int64_t seg_begin = 0, seg_end = k;
-    if (cls) {
-        const int64_t ci = cls[i];
-        int64_t lo = i + 1, hi = k;
-        while (lo < hi) {
-            int64_t mid = (lo + hi) >> 1;
-            if (cls[mid] <= ci) lo = mid + 1; else hi = mid;
-        }
-        seg_end = lo;
-        lo = 0; hi = i;
-        while (lo < hi) {
-            int64_t mid = (lo + hi) >> 1;
-            if (cls[mid] < ci) lo = mid + 1; else hi = mid;
-        }
-        seg_begin = lo;
-    }
+    if (cls) wave_class_segment(cls, k, i, seg_begin, seg_end);
     const int64_t base = seg_begin >> 6;
     const int64_t r_first = ((i + 1) >> 6) - base;
     int64_t r_last = ((seg_end - 1) >> 6) - base;
@@ -999,15 +1004,7 @@ __global__ __launch_bounds__(kSweepBlock) void nms_sweep_kernel(const unsigned l
         if (s >= k) break;
         if (cls ? (s > 0 && cls[s] == cls[s - 1]) : (s > 0)) continue;
         int64_t seg_end = k;
-        if (cls) {
-            const int64_t cs = cls[s];
-            int64_t lo = s + 1, hi = k;
-            while (lo < hi) {
-                int64_t mid = (lo + hi) >> 1;
-                if (cls[mid] <= cs) lo = mid + 1; else hi = mid;
-            }
-            seg_end = lo;
-        }
+        if (cls) { int64_t unused; wave_class_segment(cls, k, s, unused, seg_end, false); }
         // blocks of 64 rows, numbered relative to the segment's first block (the mask rows use the same numbering)
         const int64_t base = s >> 6;
         int b_last = (int)(((seg_end - 1) >> 6) - base);
@@ -1073,6 +1070,180 @@ __global__ __launch_bounds__(kSweepBlock) void nms_sweep_kernel(const unsigned l
             }
             __syncthreads();
         }
+    }
+}
+
+// ---- batched NMS without the host (sph_batched_nms, sphdet/bbox/nms/sph_nms.py:22-60, for K <= 16 384 candidates) ----
+// The reference sorts per class on the host and loops; round 2 sorted with two stable torch sorts (2 x ~30 us of rocPRIM
+// passes at K = 5 000), a scatter, a masked gather and their launch gaps: 0.18 ms around 26 us of kernels.  Here:
+//   nms_prepare_kernel   composite 64-bit keys (class | descending score | index), unique by construction, and a RANK sort:
+//                        position of a box = number of smaller keys — K^2 compares (25 M at K = 5 000) spread over the whole
+//                        chip, every workgroup holding all keys in LDS (64 boxes x 8 key ranges per workgroup; a one-workgroup
+//                        bitonic network in LDS was built first: LDS-bandwidth-bound, ~70 us per sort) -> boxes / classes in
+//                        (class, -score) order, the permutation and the (descending score | index) keys in that order;
+//   mask + sweep         as before, on the full k x (k / 64 + 2) layout (no segment width needed from the host);
+//   nms_select_kernel    the same rank sort among the KEPT boxes by (descending score | index) -> the first max_num kept indices
+//                        in the reference's final order (:49-52), dets = (box, score), and their count.
+// Ties are broken by the original index (stable), as in round 2.  One host read (the count) sizes the outputs.
+__device__ __forceinline__ unsigned desc_score_bits(float v) {   // larger score -> smaller unsigned
+    unsigned u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ~u;
+}
+constexpr int kNmsIdxBits = 14, kNmsClsBits = 18;   // K <= 16 384 candidates, class ids in [0, 262 143]
+__device__ __forceinline__ unsigned long long nms_class_key(int64_t c, float score, int j) {
+    return ((unsigned long long)(c & (((int64_t)1 << kNmsClsBits) - 1)) << (32 + kNmsIdxBits)) |
+           ((unsigned long long)desc_score_bits(score) << kNmsIdxBits) | (unsigned)j;
+}
+// Rank of IPW keys among all keys, the keys held in REGISTERS: wave w of the workgroup holds the slice [w * T * 64, (w + 1) * T * 64)
+// of the key sequence, one key per lane and register (coalesced loads, no LDS); the key whose rank is wanted is wave-uniform
+// (v_readlane -> SGPR pair), one v_cmp_lt_u64 tests it against 64 keys and s_bcnt1 counts.  (First form: all keys in LDS, the
+// wanted keys one per lane, the others read as LDS broadcasts — one LDS instruction per 64 compares made the CU's single LDS
+// the limiter: 12.4 us per launch at K = 5 000; a one-workgroup bitonic network in LDS before that: ~70 us.)
+// `mine`: lane a < IPW holds the key of the workgroup's a-th box.  Returns, in lanes a < IPW of EVERY wave, the number of keys
+// below it; `part` is (BS / 64) x 64 ints of LDS.
+// (Every slice register takes part in every test — the padding keys are ~0, never below anything: with a per-register
+// `t < tcount` skip each test sat behind its own scalar branch and the v_cmp -> s_bcnt1 pairs ran one by one, 6 us per launch.)
+template <int T, int IPW, int BS>
+__device__ __forceinline__ int rank_against_slices(const unsigned long long (&key)[T], unsigned long long mine, int (*part)[64]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned mlo = (unsigned)mine, mhi = (unsigned)(mine >> 32);
+    // per-lane counters, one per wanted key: v_cmp + v_addc per test, no scalar round trip (popcount of each compare's mask
+    // on the scalar unit cost ~75 cycles per test: 0.6 us per slice register); the lanes are added up once at the end
+    unsigned long long ka[IPW];
+#pragma unroll
+    for (int a = 0; a < IPW; a++)
+        ka[a] = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mhi, a) << 32) | (unsigned)__builtin_amdgcn_readlane((int)mlo, a);
+    int cnt[IPW];
+#pragma unroll
+    for (int a = 0; a < IPW; a++) cnt[a] = 0;
+    // (the borrow of key - ka added with carry — three full-rate instructions in place of v_cmp_lt_u64 + v_cndmask + v_add — was
+    // measured too: not faster; what sets the time is how many workgroups a CU has to run one after the other, see the launcher)
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+#pragma unroll
+        for (int a = 0; a < IPW; a++) cnt[a] += key[t] < ka[a] ? 1 : 0;
+    }
+    int mycnt = 0;
+#pragma unroll
+    for (int a = 0; a < IPW; a++) {
+        int v = cnt[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        mycnt = lane == a ? v : mycnt;
+    }
+    part[wave][lane] = mycnt;
+    __syncthreads();
+    int r = 0;
+#pragma unroll
+    for (int w = 0; w < BS / 64; w++) r += part[w][lane];
+    return r;
+}
+template <int T, int DIM, int IPW, int BS>
+__global__ __launch_bounds__(BS) void nms_prepare_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                                const int64_t* __restrict__ idxs, int k,
+                                                                float* __restrict__ boxes_sorted, int64_t* __restrict__ cls_sorted,
+                                                                int* __restrict__ order, unsigned long long* __restrict__ skey_sorted,
+                                                                int* __restrict__ status) {
+    __shared__ int part[BS / 64][64];   // (T keys per lane)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tcount = ((k + BS - 1) / BS);   // registers in use: the slices cover [0, tcount * BS)
+    unsigned long long key[T];
+    int bad = 0;
+    // every load of the kernel — the slice, this workgroup's own boxes' scores / classes AND their coordinates (the gather at
+    // the end depends on i only, not on the rank) — is requested here, before the first key is built: one round trip to memory
+    // instead of three (first form: 11 us per launch, latency-bound)
+    const int i = blockIdx.x * IPW + lane, ic = i < k ? i : k - 1;
+    const float si = scores[ic];
+    const int64_t ci = idxs ? idxs[ic] : 0;
+    float bx[5];
+    load_box<DIM>(boxes, ic, bx);
+    {
+        float sc[T];
+        int64_t cl[T];
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const int j = (wave * tcount + t) * 64 + lane, jc = j < k ? j : k - 1;
+            sc[t] = scores[jc];
+            cl[t] = idxs ? idxs[jc] : 0;
+        }
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const int j = (wave * tcount + t) * 64 + lane;
+            const bool in = t < tcount && j < k;
+            bad |= in && (cl[t] < 0 || cl[t] >= ((int64_t)1 << kNmsClsBits));
+            key[t] = in ? nms_class_key(cl[t], sc[t], j) : ~0ull;
+        }
+    }
+    const unsigned long long mine = nms_class_key(ci, si, ic);
+    bad = __syncthreads_or(bad);   // every workgroup sees every class id: all agree, the first one reports
+    if (blockIdx.x == 0 && threadIdx.x == 0) *status = bad ? -1 : 0;   // -1: a class id outside the key's field, the caller takes the general route
+    const int r = rank_against_slices<T, IPW, BS>(key, mine, part);
+    if (threadIdx.x < IPW && i < k) {
+        order[r] = i;
+        cls_sorted[r] = (int64_t)(mine >> (32 + kNmsIdxBits));
+        skey_sorted[r] = ((unsigned long long)desc_score_bits(si) << 32) | (unsigned)i;
+        if (DIM == 4) reinterpret_cast<float4*>(boxes_sorted)[r] = make_float4(bx[0], bx[1], bx[2], bx[3]);
+        else {
+#pragma unroll
+            for (int c = 0; c < 5; c++) boxes_sorted[(int64_t)r * 5 + c] = bx[c];
+        }
+    }
+}
+// (dets come from the SORTED boxes and the score inside the key: everything the kernel reads is indexed by the sorted position,
+// nothing by a loaded value — one round trip)
+__device__ __forceinline__ float score_of_desc_bits(unsigned d) {
+    const unsigned u = ~d;
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+template <int T, int DIM, int IPW, int BS>
+__global__ __launch_bounds__(BS) void nms_select_kernel(const float* __restrict__ boxes_sorted,
+                                                               const unsigned char* __restrict__ keep_sorted,
+                                                               const unsigned long long* __restrict__ skey_sorted, int k, int max_num,
+                                                               int64_t* __restrict__ keep_out, float* __restrict__ dets,
+                                                               int* __restrict__ status) {
+    __shared__ int part[BS / 64][64];
+    __shared__ int kept_waves[BS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tcount = ((k + BS - 1) / BS);
+    unsigned long long key[T];
+    int kept_here = 0;   // wave-uniform
+    const int r = blockIdx.x * IPW + lane, rc = r < k ? r : k - 1;
+    const unsigned char my_keep = keep_sorted[rc];
+    const unsigned long long my_skey = skey_sorted[rc];
+    float bx[5];
+    load_box<DIM>(boxes_sorted, rc, bx);
+    {
+        unsigned char kp[T];
+        unsigned long long sk[T];
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const int j = (wave * tcount + t) * 64 + lane, jc = j < k ? j : k - 1;
+            kp[t] = keep_sorted[jc];
+            sk[t] = skey_sorted[jc];
+        }
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const int j = (wave * tcount + t) * 64 + lane;
+            const bool kept = t < tcount && j < k && kp[t] != 0;
+            key[t] = kept ? sk[t] : ~0ull;
+            kept_here += __popcll(__builtin_amdgcn_ballot_w64(kept));
+        }
+    }
+    if (lane == 0) kept_waves[wave] = kept_here;
+    const unsigned long long mine = (r < k && my_keep != 0) ? my_skey : ~0ull;
+    const int pos = rank_against_slices<T, IPW, BS>(key, mine, part);   // (its barrier also publishes kept_waves)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && *status >= 0) {
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < BS / 64; w++) total += kept_waves[w];
+        *status = total < max_num ? total : max_num;
+    }
+    if (threadIdx.x < IPW && mine != ~0ull && pos < max_num) {
+        keep_out[pos] = (int64_t)(unsigned)mine;
+#pragma unroll
+        for (int c = 0; c < DIM; c++) dets[(int64_t)pos * (DIM + 1) + c] = bx[c];
+        dets[(int64_t)pos * (DIM + 1) + DIM] = score_of_desc_bits((unsigned)(mine >> 32));
     }
 }
 
@@ -1809,25 +1980,21 @@ int64_t sph2pob_nms_segmented_workspace_bytes(int64_t k, int64_t max_segment) {
     return k * nms_row_words(k, max_segment < 1 ? 1 : max_segment) * 8;
 }
 
-int sph2pob_nms_segmented_f32(const float* boxes_sorted, const int64_t* cls_sorted, int64_t k, int box_dim,
-                              int variant_flags, float iou_threshold, int64_t max_segment, void* workspace,
-                              unsigned char* keep, void* stream) {
+static int nms_check_options(int box_dim, int variant_flags) {
     const int variant = variant_flags & 0xff;
-    const bool fast = !(variant_flags & SPH2POB_FLAG_REFERENCE_ORDER);
     // SPH2POB_FLAG_ROBUST_PARALLEL is accepted and has no effect here (a near-parallel pair is far above any threshold)
     if (variant_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER | SPH2POB_FLAG_ROBUST_PARALLEL)) return SPH2POB_ERR_OPTION;
     if (box_dim != 4 && box_dim != 5) return SPH2POB_ERR_DIM;
     if (variant != SPH2POB_VARIANT_STANDARD && variant != SPH2POB_VARIANT_EFFICIENT && variant != SPH2POB_VARIANT_UNBIASED &&
         variant != SPH2POB_VARIANT_NAIVE)
         return SPH2POB_ERR_OPTION;
-    if (k < 0 || k > ((int64_t)1 << 31) - 64 || max_segment < 0 || max_segment > sph2pob_nms_max_boxes())
-        return SPH2POB_ERR_SIZE;
-    if (k == 0) return SPH2POB_OK;
-    if (!boxes_sorted || !workspace || !keep) return SPH2POB_ERR_NULL;
-    if (!cls_sorted && max_segment < k) return SPH2POB_ERR_SIZE;  // one segment: it is k long
-    hipStream_t s = (hipStream_t)stream;
-    const int words = (int)nms_row_words(k, max_segment < 1 ? 1 : max_segment);
-    unsigned long long* mask = (unsigned long long*)workspace;
+    return SPH2POB_OK;
+}
+// mask + sweep on boxes sorted by (class, -score): the two launches every NMS entry point shares
+static int nms_mask_and_sweep(const float* boxes_sorted, const int64_t* cls_sorted, int64_t k, int box_dim, int variant_flags,
+                              float iou_threshold, int words, unsigned long long* mask, unsigned char* keep, hipStream_t s) {
+    const int variant = variant_flags & 0xff;
+    const bool fast = !(variant_flags & SPH2POB_FLAG_REFERENCE_ORDER);
     const int wpb = kBlock / 64;
     dim3 grid((unsigned)((k + wpb - 1) / wpb));
 #define SPH_NMS_LAUNCH(V, D, F) \
@@ -1857,6 +2024,75 @@ int sph2pob_nms_segmented_f32(const float* boxes_sorted, const int64_t* cls_sort
     if (rc) return rc;
     hipLaunchKernelGGL(nms_sweep_kernel, dim3((unsigned)((k + kSweepCands - 1) / kSweepCands)), dim3(kSweepBlock), 0, s, mask, cls_sorted, k,
                        words, keep);
+    return launch_status();
+}
+
+int sph2pob_nms_segmented_f32(const float* boxes_sorted, const int64_t* cls_sorted, int64_t k, int box_dim,
+                              int variant_flags, float iou_threshold, int64_t max_segment, void* workspace,
+                              unsigned char* keep, void* stream) {
+    int rc = nms_check_options(box_dim, variant_flags);
+    if (rc) return rc;
+    if (k < 0 || k > ((int64_t)1 << 31) - 64 || max_segment < 0 || max_segment > sph2pob_nms_max_boxes())
+        return SPH2POB_ERR_SIZE;
+    if (k == 0) return SPH2POB_OK;
+    if (!boxes_sorted || !workspace || !keep) return SPH2POB_ERR_NULL;
+    if (!cls_sorted && max_segment < k) return SPH2POB_ERR_SIZE;  // one segment: it is k long
+    return nms_mask_and_sweep(boxes_sorted, cls_sorted, k, box_dim, variant_flags, iou_threshold,
+                              (int)nms_row_words(k, max_segment < 1 ? 1 : max_segment), (unsigned long long*)workspace, keep,
+                              (hipStream_t)stream);
+}
+
+// workspace of the host-free form: sorted boxes | classes | permutation | keep flags | mask matrix (all 256-byte aligned)
+struct BatchedNmsWs { float* boxes; int64_t* cls; int* order; unsigned long long* skey; unsigned char* keep; unsigned long long* mask; int64_t bytes; int words; };
+static BatchedNmsWs batched_nms_ws(void* workspace, int64_t k, int box_dim) {
+    auto up = [](int64_t x) { return (x + 255) / 256 * 256; };
+    BatchedNmsWs w;
+    char* p = (char*)workspace;
+    w.words = (int)nms_row_words(k, k);
+    int64_t off = 0;
+    w.boxes = (float*)(p + off); off += up(k * box_dim * 4);
+    w.cls = (int64_t*)(p + off); off += up(k * 8);
+    w.order = (int*)(p + off); off += up(k * 4);
+    w.skey = (unsigned long long*)(p + off); off += up(k * 8);
+    w.keep = (unsigned char*)(p + off); off += up(k);
+    w.mask = (unsigned long long*)(p + off); off += up(k * (int64_t)w.words * 8);
+    w.bytes = off;
+    return w;
+}
+int sph2pob_batched_nms_max_boxes(void) { return 1 << kNmsIdxBits; }
+int64_t sph2pob_batched_nms_workspace_bytes(int64_t k, int box_dim) {
+    return k > 0 && k <= sph2pob_batched_nms_max_boxes() ? batched_nms_ws(nullptr, k, box_dim).bytes : 0;
+}
+int sph2pob_batched_nms_f32(const float* boxes, const float* scores, const int64_t* idxs, int64_t k, int box_dim, int variant_flags,
+                            float iou_threshold, int64_t max_num, void* workspace, int64_t* keep, float* dets, int* status,
+                            void* stream) {
+    int rc = nms_check_options(box_dim, variant_flags);
+    if (rc) return rc;
+    if (k < 0 || k > sph2pob_batched_nms_max_boxes() || max_num < 0) return SPH2POB_ERR_SIZE;
+    if (!status) return SPH2POB_ERR_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    if (k == 0 || max_num == 0) return hipMemsetAsync(status, 0, sizeof(int), s) == hipSuccess ? SPH2POB_OK : (int)hipGetLastError();
+    if (!boxes || !scores || !workspace || !keep || !dets) return SPH2POB_ERR_NULL;
+    const BatchedNmsWs w = batched_nms_ws(workspace, k, box_dim);
+    const int kk = (int)k, mx = (int)(max_num < k ? max_num : k);
+    // T keys per lane x BS threads cover the candidates, IPW boxes per workgroup, chosen so that the grid is at most 256
+    // workgroups: with ~150 VGPRs per lane a CU holds ONE of these workgroups at a time, and 313 of them (16 boxes each at
+    // K = 5 000) ran in two rounds — 12 us per launch where 6 144 candidates or fewer now take one round
+#define SPH_PREP(T, D, I, B) hipLaunchKernelGGL((nms_prepare_kernel<T, D, I, B>), dim3((unsigned)((k + I - 1) / I)), dim3(B), 0, s, boxes, scores, idxs, kk, \
+                                                w.boxes, w.cls, w.order, w.skey, status)
+#define SPH_SEL(T, D, I, B) hipLaunchKernelGGL((nms_select_kernel<T, D, I, B>), dim3((unsigned)((k + I - 1) / I)), dim3(B), 0, s, (const float*)w.boxes, \
+                                               (const unsigned char*)w.keep, (const unsigned long long*)w.skey, kk, mx, keep, dets, status)
+#define SPH_BY_SIZE(M, D) do { if (k <= 2048) M(4, D, 16, 512); else if (k <= 4096) M(8, D, 16, 512); else if (k <= 6144) M(12, D, 24, 512); \
+                               else if (k <= 8192) M(16, D, 32, 512); else if (k <= 12288) M(12, D, 48, 1024); else M(16, D, 64, 1024); } while (0)
+    if (box_dim == 4) SPH_BY_SIZE(SPH_PREP, 4); else SPH_BY_SIZE(SPH_PREP, 5);
+    rc = launch_status();
+    if (rc) return rc;
+    rc = nms_mask_and_sweep(w.boxes, idxs ? w.cls : nullptr, k, box_dim, variant_flags, iou_threshold, w.words, w.mask, w.keep, s);
+    if (rc) return rc;
+    if (box_dim == 4) SPH_BY_SIZE(SPH_SEL, 4); else SPH_BY_SIZE(SPH_SEL, 5);
+#undef SPH_PREP
+#undef SPH_SEL
+#undef SPH_BY_SIZE
     return launch_status();
 }
 

@@ -65,12 +65,17 @@ def test_bench_single_process_contract():
     p = d['parity']
     assert p['pairs'] == 1_000_000 and p['fast']['benched'] is True and p['reference_order']['benched'] is False
     for arm in ('fast', 'reference_order'):
-        for ref in ('vs_ref32', 'vs_f64'):
-            st = p[arm][ref]
-            assert set(st) == {'max', 'mean', 'p99_9', 'n_gt_1e-5', 'n_gt_1e-4'}
-            # the benchmark distribution: a handful of pairs per million beyond 1e-5, none beyond 1e-4
-            assert st['mean'] < 1e-6 and st['p99_9'] < 1e-5 and st['n_gt_1e-5'] <= 25 and st['n_gt_1e-4'] == 0 and st['max'] < 1e-4
-    assert p['ref32_vs_f64']['n_gt_1e-5'] <= 25
+        for ref in ('vs_ref32', 'vs_ref32_diff', 'vs_f64'):
+            assert set(p[arm][ref]) == {'max', 'mean', 'p99_9', 'n_gt_1e-5', 'n_gt_1e-4'}
+        # the benchmark distribution against f64 (measured, profiles/r05h_bench.json: fast 5 pairs > 1e-5, max 1.6e-5;
+        # reference order 17 pairs, max 3.6e-5): a handful of pairs per million beyond 1e-5, none beyond 1e-4
+        t = p[arm]['vs_f64']
+        assert t['mean'] < 1e-6 and t['p99_9'] < 1e-5 and t['n_gt_1e-5'] <= 30 and t['n_gt_1e-4'] == 0 and t['max'] < 1e-4
+        # against the reference's fp32 arithmetic: what ref32 itself is away from f64, plus that handful (this batch holds
+        # two pairs on which mmcv's hull is 0.15 off: ref32_vs_f64 n_gt_1e-4 = 2, and the kernel is with f64 on both)
+        for ref, own in (('vs_ref32', 'ref32_vs_f64'), ('vs_ref32_diff', 'ref32_diff_vs_f64')):
+            r = p[arm][ref]
+            assert r['mean'] < 1e-6 and r['n_gt_1e-5'] <= p[own]['n_gt_1e-5'] + 30 and r['n_gt_1e-4'] <= p[own]['n_gt_1e-4']
     assert p['reference_order']['kernel_ms'] > p['fast']['kernel_ms']
 
 

@@ -58,13 +58,43 @@ def test_product_never_imports_oracle():
                 assert 'libsph2pob_oracle' not in text, os.path.join(dirpath, f)
 
 
-def test_cpu_tensors_fail_loudly():
+def test_host_library_exports_every_cpu_twin_and_never_links_the_oracle():
+    """libsph2pob_host.so (CPU twins `<name>_cpu`) is product code: built from sph_retina_amd/csrc only, it must
+    export a twin for every name in _lib.HOST_TWINS with the HIP entry's signature, and must not include, link or load
+    anything under oracle/."""
+    import subprocess
+    from sph_retina_amd import _lib
+    _lib.build()
+    handle = ctypes.CDLL(_lib.HOST_LIB_PATH)
+    for name in _lib.HOST_TWINS:
+        assert name in _lib.SIGNATURES and hasattr(handle, name + '_cpu'), name
+    src = open(os.path.join(_lib.CSRC, _lib.HOST_SOURCES[0])).read()
+    includes = re.findall(r'#include\s+"([^"]+)"', src)
+    assert includes and all('oracle' not in i for i in includes), includes
+    assert all(os.path.normpath(os.path.join(_lib.CSRC, i)).startswith((os.path.join(ROOT, 'sph_retina_amd'), os.path.join(ROOT, 'include')))
+               for i in includes), includes
+    needed = subprocess.run(['ldd', _lib.HOST_LIB_PATH], capture_output=True, text=True).stdout
+    assert 'oracle' not in needed
+    assert all('oracle' not in f for f in _lib.HOST_FLAGS + _lib.HOST_SOURCES)
+    null = ctypes.c_void_p(0)
+    lib = _lib.host_lib()
+    assert lib.sph2pob_iou_aligned_f32_cpu(null, null, null, 0, 4, 0, 0, 0, 0, null) == 0
+    assert lib.sph2pob_iou_aligned_f32_cpu(null, null, null, 10, 4, 0, 0, 0, 0, null) == -1
+    assert lib.sph2pob_iou_aligned_f32_cpu(null, null, null, 10, 5, 2, 0, 0, 0, null) == -2
+    assert lib.sph2pob_host_threads() >= 1
+
+
+def test_mixed_devices_and_bad_options_fail_loudly():
     import torch
     import sph_retina_amd as S
-    with pytest.raises(RuntimeError, match='HIP'):
-        S.sph2pob_standard_iou(torch.rand(4, 4), torch.rand(4, 4))
-    # empty inputs never reach the device (reference: sph_iou_api.py:56-57)
+    # empty inputs never reach a library (reference: sph_iou_api.py:56-57)
     assert S.sph2pob_standard_iou(torch.rand(0, 4), torch.rand(3, 4)).shape == (0, 3)
     assert S.sph2pob_efficient_iou(torch.rand(0, 4), torch.rand(0, 4), is_aligned=True).shape == (0, 1)
     with pytest.raises(AssertionError):
         S.sph2pob_standard_iou(torch.rand(4, 4), torch.rand(4, 4), mode='giou')
+    with pytest.raises(RuntimeError, match='MI355X'):
+        S.sph2pob_standard_iou(torch.rand(4, 4), torch.rand(4, 4, device='meta'))
+    # operators without a CPU twin say so instead of falling back
+    from sph_retina_amd.bbox.assigners import fused_assign
+    with pytest.raises(RuntimeError, match='MI355X'):
+        fused_assign(torch.rand(2, 4) * 50 + 20, torch.rand(9, 4) * 50 + 20)

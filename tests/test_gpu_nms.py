@@ -182,3 +182,88 @@ def test_long_single_class_segment_through_the_pipelined_sweep(N, oracle):
 
 def s_sorted_desc(t):
     return torch.sort(t, descending=True, stable=True)[0]
+
+
+# ---- round 3: the host-free route (sph2pob_batched_nms_f32) and the chunked sweep of over-long classes ----
+def _general_route(N, boxes, scores, idxs, cfg, variant='efficient'):
+    """sph_batched_nms with the host-free route switched off: torch sorts + the same two NMS kernels (round 2's path)."""
+    from sph_retina_amd import _lib
+    lib = _lib.lib()
+    real = lib.sph2pob_batched_nms_max_boxes
+    try:
+        lib.sph2pob_batched_nms_max_boxes = lambda: 0
+        return N.sph_batched_nms(boxes, scores, idxs, cfg, variant)
+    finally:
+        lib.sph2pob_batched_nms_max_boxes = real
+
+
+@pytest.mark.parametrize('k,dim,ncls', [(1, 4, 1), (63, 4, 3), (2048, 4, 37), (2049, 5, 5), (5000, 4, 37), (8192, 4, 2), (16384, 4, 80)])
+def test_host_free_route_equals_general_route(N, oracle, k, dim, ncls):
+    rng = np.random.default_rng(k + dim)
+    centres = oracle.generate_boxes(max(k // 16, 1), 8, box='bfov' if dim == 4 else 'rbfov', alpha=(5, 60), beta=(5, 60))
+    b = centres[rng.integers(0, len(centres), k)] + rng.standard_normal((k, dim)).astype(np.float32) * 2.0
+    b[:, 0] %= 360
+    b[:, 1] = b[:, 1].clip(1, 179)
+    b[:, 2:4] = b[:, 2:4].clip(2, 120)
+    scores = rng.random(k).astype(np.float32)
+    scores[rng.integers(0, k, k // 8)] = np.float32(0.5)        # many exact score ties: broken by the original index
+    idxs = rng.integers(0, ncls, k)
+    tb, ts, ti = cu(b), cu(scores), cu(idxs)
+    for cfg in (dict(type='nms', iou_threshold=0.5, max_num=100), dict(type='nms', iou_threshold=0.3)):
+        dets, keep = N.sph_batched_nms(tb, ts, ti, cfg, 'efficient')
+        gdets, gkeep = _general_route(N, tb, ts, ti, cfg)
+        assert torch.equal(keep, gkeep) and torch.equal(dets, gdets)
+        assert keep.dtype == torch.int64 and dets.shape == (keep.numel(), dim + 1)
+    if k == 5000:   # and against the CPU restatement of the reference's loop
+        odets, okeep = oracle.batched_nms(b, scores, idxs, 0.5, max_num=100)
+        dets, keep = N.sph_batched_nms(tb, ts, ti, dict(iou_threshold=0.5, max_num=100), 'efficient')
+        sk = scores[keep.cpu().numpy()]
+        assert (np.diff(sk) <= 0).all() and len(set(keep.tolist()) ^ set(okeep.tolist())) <= 2
+
+
+def test_host_free_route_leaves_inputs_alone_and_handles_odd_class_ids(N):
+    g = torch.Generator().manual_seed(3)
+    k = 900
+    b = torch.stack([torch.rand(k, generator=g) * 40 + 100, torch.rand(k, generator=g) * 30 + 70,
+                     torch.rand(k, generator=g) * 30 + 5, torch.rand(k, generator=g) * 30 + 5], 1).cuda()
+    s = torch.rand(k, generator=g).cuda()
+    cfg = dict(iou_threshold=0.5)
+    small = torch.randint(0, 5, (k,), generator=g).cuda()
+    b0, s0 = b.clone(), s.clone()
+    d1, k1 = N.sph_batched_nms(b, s, small, cfg)
+    assert torch.equal(b, b0) and torch.equal(s, s0)
+    # class ids beyond the composite key's 18 bits, and negative ones: the call silently takes the general route — same result
+    for ids in (small * 1_000_003, small - 3, small.to(torch.int32)):
+        d2, k2 = N.sph_batched_nms(b, s, ids, cfg)
+        assert torch.equal(k1, k2) and torch.equal(d1, d2)
+
+
+def test_one_class_of_40000_boxes_is_swept_in_chunks(N, oracle):
+    """A class beyond the sweep kernel's 32 704 boxes (round 2 raised; the reference has no limit, sph_nms.py:62-74):
+    chunks of 16 384, each first tested against every box kept so far.  Keep list against the CPU restatement of the loop."""
+    rng = np.random.default_rng(40)
+    k = 40000
+    centres = oracle.generate_boxes(4000, 9, alpha=(3, 25), beta=(3, 25))
+    b = centres[rng.integers(0, 4000, k)] + rng.normal(0, 1.0, (k, 4)).astype(np.float32)
+    b[:, 0] %= 360
+    b[:, 1] = np.clip(b[:, 1], 1, 179)
+    b[:, 2:] = np.clip(b[:, 2:], 1, 120)
+    s = rng.random(k).astype(np.float32)
+    keep = N.sph_nms_op(cu(b), cu(s), 0.5)
+    ref = oracle.nms_op(b, s, 0.5, variant='efficient', nthreads=16)
+    got, want = set(keep.tolist()), set(ref.tolist())
+    assert len(want) > 3000 and len(got ^ want) <= 8, (len(got), len(want), len(got ^ want))
+    sk = s[keep.cpu().numpy()]
+    assert (np.diff(sk) <= 0).all()
+    # the same class inside a multi-class call: the long class in chunks, the others through the kernels
+    idxs = np.zeros(k + 600, np.int64)
+    idxs[k:] = rng.integers(1, 4, 600)
+    b2 = np.concatenate([b, b[:600] + np.float32(0.3)])
+    s2 = np.concatenate([s, rng.random(600).astype(np.float32)])
+    dets, keep2 = N.SphNMS()(cu(b2), cu(s2), cu(idxs), dict(iou_threshold=0.5))
+    k2 = keep2.cpu().numpy()
+    assert set(k2[k2 < k].tolist()) == got
+    rest = np.nonzero(idxs > 0)[0]
+    _, kr = N.SphNMS()(cu(b2[rest]), cu(s2[rest]), cu(idxs[rest]), dict(iou_threshold=0.5))
+    assert set(rest[kr.cpu().numpy()].tolist()) == set(k2[k2 >= k].tolist())
+    assert (np.diff(s2[k2]) <= 0).all()

@@ -17,6 +17,7 @@ Workloads (all through the C ABI, buffers allocated once, HIP events around `--l
   fused     sph2pob_iou_assign_f32 (no matrix) on the same
   loss      sph2pob_loss_fwd_grad_f32 + final sum + grad_scale, 1 M nearby RBFoV pairs, CIoU (configs[2])
   nms       sph2pob_nms_segmented_f32 on 5 000 sorted boxes x 37 classes and on one class of 5 000
+  bnms      sph2pob_batched_nms_f32 (unsorted input, no host work) on the same two scenes
 Every arm's outputs are compared with the first arm's (bit equality is reported, not assumed).
 """
 import argparse
@@ -167,7 +168,7 @@ def workloads(args, torch, G):
                     return rc | lib.sph2pob_loss_grad_scale_f32(G.ptr(gp), G.ptr(one), 0, G.ptr(gp), n, 5, st)
                 return launch, [out, gp]
             yield f'loss {mode_name} fwd+grad 1 M RBFoV', make
-    elif args.workload == 'nms':
+    elif args.workload in ('nms', 'bnms'):
         import numpy as np
         from tools.bench_configs import boxes
         k = 5000
@@ -183,6 +184,18 @@ def workloads(args, torch, G):
             order = torch.argsort(cls.double() * 2 - scores.double(), stable=True)
             bs, cs = torch.from_numpy(b)[order].cuda().contiguous(), cls[order].cuda().contiguous()
             seg = int(torch.bincount(cls).max())
+
+            if args.workload == 'bnms':
+                ub, us, uc = torch.from_numpy(b).cuda().contiguous(), scores.cuda(), (cls.cuda() if title.endswith('classes') else None)
+                mx = 100 if uc is not None else k
+
+                def make(lib, ub=ub, us=us, uc=uc, mx=mx):
+                    ws = torch.empty(lib.sph2pob_batched_nms_workspace_bytes(k, 4), dtype=torch.uint8, device='cuda')
+                    ko, do, stt = torch.zeros(mx, dtype=torch.int64, device='cuda'), torch.zeros((mx, 5), device='cuda'), torch.zeros(1, dtype=torch.int32, device='cuda')
+                    return (lambda: lib.sph2pob_batched_nms_f32(G.ptr(ub), G.ptr(us), G.ptr(uc), k, 4, 1, 0.5, mx, G.ptr(ws), G.ptr(ko), G.ptr(do),
+                                                                G.ptr(stt), st)), [ko, do, stt]
+                yield f'bnms {title}', make
+                continue
 
             def make(lib, bs=bs, cs=cs, seg=seg):
                 keep = torch.empty(k, dtype=torch.uint8, device='cuda')

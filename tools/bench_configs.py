@@ -197,12 +197,22 @@ def config4(h=512, w=1024):
     cfg = dict(type='nms', iou_threshold=0.5, max_num=100)
     t_nms = timeit(lambda: nms(nb, ns, ni, cfg), reps=20)
     t_nms1 = timeit(lambda: nms(nb, ns, torch.zeros_like(ni), cfg), reps=10)
+    # the launcher alone (buffers allocated once, no host read of the count): what a captured graph or a C++ caller pays
+    wsn = torch.empty(lib.sph2pob_batched_nms_workspace_bytes(k, 4), dtype=torch.uint8, device='cuda')
+    kout, dout, stat = torch.empty(100, dtype=torch.int64, device='cuda'), torch.empty((100, 5), device='cuda'), torch.empty(1, dtype=torch.int32, device='cuda')
+    ni64 = ni.to(torch.int64)
+    t_nms_abi = timeit(lambda: lib.sph2pob_batched_nms_f32(G.ptr(nb), G.ptr(ns), G.ptr(ni64), k, 4, 1, 0.5, 100, G.ptr(wsn), G.ptr(kout),
+                                                            G.ptr(dout), G.ptr(stat), st), reps=100)
+    kall, dall = torch.empty(k, dtype=torch.int64, device='cuda'), torch.empty((k, 5), device='cuda')
+    t_nms1_abi = timeit(lambda: lib.sph2pob_batched_nms_f32(G.ptr(nb), G.ptr(ns), None, k, 4, 1, 0.5, k, G.ptr(wsn), G.ptr(kall),
+                                                             G.ptr(dall), G.ptr(stat), st), reps=50)
     m, n = ov.shape
     return {'config': 'configs[3]: MaxIoUAssigner overlaps 64 GT x %d anchors (%dx%d ERP grid) + SphNMS 5000 boxes' % (n, h, w),
             'pairs': m * n, 'iou_matrix_ms': t_iou * 1e3, 'pairs_per_s': m * n / t_iou,
             'iou_plus_torch_max_argmax_ms': t_assign * 1e3, 'fused_assign_total_ms': t_fused * 1e3, 'matrix_assign_total_ms': t_matrix * 1e3,
             'fused_assign_c_abi_ms': t_fused_abi * 1e3, 'matrix_assign_c_abi_ms': t_matrix_abi * 1e3, 'frac_pairs_overlapping': float((ov > 0).float().mean()),
-            'nms_5000x37cls_ms': t_nms * 1e3, 'nms_5000_single_class_ms': t_nms1 * 1e3}
+            'nms_5000x37cls_ms': t_nms * 1e3, 'nms_5000_single_class_ms': t_nms1 * 1e3,
+            'nms_5000x37cls_c_abi_ms': t_nms_abi * 1e3, 'nms_5000_single_class_c_abi_ms': t_nms1_abi * 1e3}
 
 
 def coder(n=1_000_000):
