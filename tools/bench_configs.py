@@ -36,6 +36,27 @@ def timeit(fn, warm=5, reps=30, settle_s=0.03):
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
+def pmc_roofline(kernel_prefix, seconds, algorithmic_bytes, grid=None):
+    """What bounds a kernel, from this round's committed counter passes (profiles/configs_pmc_summary.json, made by
+    tools/profile_configs_pmc.sh + tools/summarize_configs_pmc.py): HBM-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, the
+    guide's gfx950 correction) and the VALU issue-slot fraction, next to the algorithmic bytes and THIS run's time."""
+    out = {'algorithmic_bytes': algorithmic_bytes, 'hbm_frac_algorithmic': algorithmic_bytes / seconds / 8e12 if algorithmic_bytes else None}
+    try:
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'configs_pmc_summary.json')) as f:
+            ks = json.load(f)['kernels']
+    except (OSError, ValueError):
+        return out
+    cands = [e for k, e in ks.items() if e['kernel'].startswith(kernel_prefix) and (grid is None or e['grid_threads'] == grid)]
+    if not cands:
+        return out
+    e = max(cands, key=lambda c: c['grid_threads'])
+    out.update(kernel=e['kernel'], counter_bytes=e.get('hbm_bytes'), fetch_calibrated=e.get('fetch_calibrated'),
+               hbm_frac_counter_bytes=(e['hbm_bytes'] / seconds / 8e12) if e.get('hbm_bytes') else None,
+               valu_issue_frac=e.get('valu_issue_frac'), valu_insts_per_wave=e.get('valu_insts_per_wave'), binds=e.get('binds'),
+               profiled_kernel_us=e['avg_ns'] / 1e3, source='profiles/configs_pmc_summary.json')
+    return out
+
+
 def boxes(n, seed, dim=4, alpha=(1, 100), gamma=(-90, 90)):
     g = torch.Generator().manual_seed(seed)
     u = torch.rand((n, 5), generator=g)
@@ -118,6 +139,7 @@ def config3(n=1_000_000):
             'c_abi_two_pass_fwd_bwd_ms': tb * 1e3, 'c_abi_fwd_bwd_scaled_grad_ms': ts * 1e3, 'graph_replay_fwd_bwd_ms': tg * 1e3 if tg else None,
             'pairs_per_s_c_abi': n / ta, 'pairs_per_s_autograd': n / t, 'pairs_per_s_graph_replay': n / tg if tg else None,
             'algorithmic_bytes_per_pair': 108, 'hbm_GBps_c_abi': 108 * n / ta / 1e9,
+            'roofline': pmc_roofline('loss_fwd_grad_kernel', ta, 60.0 * n),
             'hbm_frac_of_8TBps_c_abi': 108 * n / ta / 8e12,
             'note': 'c_abi = loss_fwd_grad (forward + gradients + per-workgroup partial sums in one pass) + final sum + '
                     'grad_scale through the C ABI; two_pass = loss_fwd_sum + final sum + loss_bwd (recomputes the forward); '
@@ -207,12 +229,15 @@ def config4(h=512, w=1024):
     t_nms1_abi = timeit(lambda: lib.sph2pob_batched_nms_f32(G.ptr(nb), G.ptr(ns), None, k, 4, 1, 0.5, k, G.ptr(wsn), G.ptr(kall),
                                                              G.ptr(dall), G.ptr(stat), st), reps=50)
     m, n = ov.shape
+    roof = {'pairwise': pmc_roofline('iou_pairwise_compact_kernel<0, 4, true, 1>', t_iou, 16.0 * (m + n) + 4.0 * m * n, grid=((n + 255) // 256) * 256 * (8 if n < 200000 else 3)),
+            'fused_phase1': pmc_roofline('iou_pairwise_compact_kernel<0, 4, true, 2>', t_fused_abi, 16.0 * (m + n), grid=((n + 255) // 256) * 256 * (8 if n < 200000 else 3)),
+            'nms_mask': pmc_roofline('nms_mask_compact_kernel', t_nms_abi, None), 'nms_sweep': pmc_roofline('nms_sweep_kernel', t_nms_abi, None)}
     return {'config': 'configs[3]: MaxIoUAssigner overlaps 64 GT x %d anchors (%dx%d ERP grid) + SphNMS 5000 boxes' % (n, h, w),
             'pairs': m * n, 'iou_matrix_ms': t_iou * 1e3, 'pairs_per_s': m * n / t_iou,
             'iou_plus_torch_max_argmax_ms': t_assign * 1e3, 'fused_assign_total_ms': t_fused * 1e3, 'matrix_assign_total_ms': t_matrix * 1e3,
             'fused_assign_c_abi_ms': t_fused_abi * 1e3, 'matrix_assign_c_abi_ms': t_matrix_abi * 1e3, 'frac_pairs_overlapping': float((ov > 0).float().mean()),
             'nms_5000x37cls_ms': t_nms * 1e3, 'nms_5000_single_class_ms': t_nms1 * 1e3,
-            'nms_5000x37cls_c_abi_ms': t_nms_abi * 1e3, 'nms_5000_single_class_c_abi_ms': t_nms1_abi * 1e3}
+            'nms_5000x37cls_c_abi_ms': t_nms_abi * 1e3, 'nms_5000_single_class_c_abi_ms': t_nms1_abi * 1e3, 'roofline': roof}
 
 
 def coder(n=1_000_000):
