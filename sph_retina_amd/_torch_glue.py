@@ -13,17 +13,21 @@ FLAG_REFERENCE_ORDER = 0x100
 _ARITHMETIC = os.environ.get('SPH2POB_ARITHMETIC', 'fast')
 if _ARITHMETIC not in ('fast', 'robust', 'reference'):
     raise ValueError(f"SPH2POB_ARITHMETIC must be 'fast', 'robust' or 'reference', got {_ARITHMETIC!r}")
+if _ARITHMETIC == 'robust':
+    _ARITHMETIC = 'fast'
 
 
-FLAG_ROBUST_PARALLEL = 0x200
+FLAG_ROBUST_PARALLEL = 0x200   # accepted by the ABI and ignored: the near-parallel safeguard has been always-on since round 2
 
 
 def set_arithmetic(mode):
-    """'fast' (default): closed-form geometry core; 'robust': the same plus the near-parallel safeguard of the aligned /
-    pairwise IoU kernels (jitter cancellation, +4.5 % time); 'reference': the reference's fp32 operation order."""
+    """'fast' (default): the closed-form geometry core, near-parallel safeguard and NaN propagation included;
+    'reference': the reference's fp32 operation order (3x the VALU work on the pairs that survive the cull; tracks the
+    reference's rounding 3x more closely on nearby pairs); 'robust': round 1's name for the safeguard
+    that is now part of 'fast' - kept as an alias."""
     global _ARITHMETIC
     assert mode in ('fast', 'robust', 'reference')
-    _ARITHMETIC = mode
+    _ARITHMETIC = 'fast' if mode == 'robust' else mode
 
 
 def get_arithmetic():
@@ -32,8 +36,7 @@ def get_arithmetic():
 
 class _Variants(dict):
     def __getitem__(self, k):
-        return _VARIANT_CODES[k] | (FLAG_REFERENCE_ORDER if _ARITHMETIC == 'reference' else 0) | \
-            (FLAG_ROBUST_PARALLEL if _ARITHMETIC == 'robust' else 0)
+        return _VARIANT_CODES[k] | (FLAG_REFERENCE_ORDER if _ARITHMETIC == 'reference' else 0)
 
 
 VARIANTS = _Variants(_VARIANT_CODES)

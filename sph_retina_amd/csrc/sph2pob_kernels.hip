@@ -1598,7 +1598,7 @@ struct AlignedLaunch {
     template <int V, int D> int run() {
         dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
         if (V <= 2 && n < ((int64_t)1 << 31) - 1024 && !g_no_compact) {
-            // persistent-style grid.  Measured on MI355X (tools/sweep_slices.sh): every CU must hold the same number of
+            // persistent-style grid.  Measured on MI355X (`tools/ab.py run --workload aligned ... label:SPH2POB_WGS_PER_CU=k`; round 1: tools/sweep_slices.sh): every CU must hold the same number of
             // workgroups (1 303 workgroups = 5.09 per CU take 12 % longer than 1 536 = 6 per CU); 6 per CU (24 waves per CU)
             // is the best or within noise of the best from 125 k to 8 M pairs; small launches want one slice per wave
             // rather than full survivor stacks.  Hence: whole multiples of the CU count, at most 6 per CU (and never
