@@ -41,11 +41,13 @@ enum { SPH2POB_VARIANT_STANDARD = 0, SPH2POB_VARIANT_EFFICIENT = 1, SPH2POB_VARI
  * Both meet the parity bar on the benchmark distribution; on close-centre pairs the closed-form core is ~10x
  * closer to fp64 truth, the reference-order path ~3x closer to the reference's own fp32 rounding. */
 enum { SPH2POB_FLAG_REFERENCE_ORDER = 0x100,
-       /* OR-ed into `variant` of the aligned / pairwise IoU entry points (closed-form core only): pairs whose planar boxes
-        * the reference's two jitter steps leave parallel to < 2.5e-4 rad (a cancellation, ~1e-6 of adversarial pairs) are
-        * evaluated with a first-order form that has no 1/sin(delta); without it those pairs can be off by up to 2e-2.
-        * Costs 4.5 % of the kernel for every pair, hence opt-in. */
-       SPH2POB_FLAG_ROBUST_PARALLEL = 0x200 };
+       /* accepted and ignored: round 1's opt-in near-parallel safeguard (pairs whose planar boxes the reference's two jitter
+        * steps leave parallel to < 2.5e-4 rad take a first-order form without 1/sin(delta)) is part of every closed-form
+        * kernel since round 2 */
+       SPH2POB_FLAG_ROBUST_PARALLEL = 0x200,
+       /* SPH2POB_VARIANT_NAIVE only: Sph2PlanarBoxTransform('sph2tan') instead of 'sph2pix' (naive_iou(box_formator=...),
+        * sphdet/iou/sph_iou_api.py:179, sphdet/bbox/box_formator.py:98-106, :166-172) */
+       SPH2POB_FLAG_NAIVE_TAN = 0x400 };
 /* mode: sphdet/iou/sph_iou_api.py:49 ('iou' | 'iof') */
 enum { SPH2POB_MODE_IOU = 0, SPH2POB_MODE_IOF = 1 };
 /* rbb_edge: sphdet/iou/sph2pob_standard.py:110-118 */

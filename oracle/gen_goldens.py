@@ -410,6 +410,19 @@ def assign_only():
     save('assign', **arrs)
 
 
+def naive_only():
+    """Naive IoU, RBFoV branch (sph_iou_api.py:179-197: Sph2PlanarBoxTransform + box_iou_rotated) with both box formators
+    ('sph2pix', 'sph2tan': box_formator.py:76-106, :161-183), aligned.  `box_iou_rotated` is the reference's vendored planar IoU
+    (mmcv absent); the BFoV branch needs mmcv.ops.bbox_overlaps and stays unpinned."""
+    torch.manual_seed(20231103)
+    g, p = gen(1500, box='rbfov', near=True, alpha=(2, 80), beta=(2, 80))
+    arrs = dict(b1=g, b2=p)
+    for f in ('sph2pix', 'sph2tan'):
+        arrs['iou_' + f] = R.api.naive_iou(g, p, is_aligned=True, box_formator=f)
+        arrs['iou64_' + f] = f64(R.api.naive_iou, g, p, is_aligned=True, box_formator=f)
+    save('naive', **arrs)
+
+
 def transform_bwd_only():
     """Gradients of the transforms that have no closed-form backward in the kernels — sph2pob_legacy and
     rbb_angle='project' of sph2pob_standard / sph2pob_efficient — from the reference's own torch autograd
@@ -483,6 +496,8 @@ if __name__ == '__main__':
         coder_only()
     elif len(sys.argv) > 1 and sys.argv[1] == 'assign':
         assign_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'naive':
+        naive_only()
     else:
         main()
         approx_only()
@@ -492,3 +507,4 @@ if __name__ == '__main__':
         samples_backends_only()
         transform_bwd_only()
         assign_only()
+        naive_only()

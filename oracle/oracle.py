@@ -411,7 +411,7 @@ def unbiased_iou(b1, b2, is_aligned=True, prec='kernel', nthreads=None):
     return out if is_aligned else out.reshape(m, n)
 
 
-def naive_iou(b1, b2, is_aligned=True, planar='mmcv'):
+def naive_iou(b1, b2, is_aligned=True, planar='mmcv', box_formator='sph2pix'):
     """naive_iou — sphdet/iou/sph_iou_api.py:179-197: Sph2PlanarBoxTransform('sph2pix'), img_size (512, 1024)
     (sphdet/bbox/box_formator.py:76-83, :161-178) then mmcv.ops.bbox_overlaps (BFoV, xyxy, offset 0) or
     mmcv.ops.box_iou_rotated (RBFoV, angle = -deg2rad(gamma)).  mmcv-full 1.6.0 is absent: bbox_overlaps is restated
@@ -426,8 +426,14 @@ def naive_iou(b1, b2, is_aligned=True, planar='mmcv'):
     f = np.float32
 
     def pix(x):
-        return np.stack([(x[:, 0] / f(360)) * f(1024), (x[:, 1] / f(180)) * f(512), (x[:, 2] / f(360)) * f(1024),
-                         (x[:, 3] / f(180)) * f(512)], axis=1).astype(f)
+        if box_formator == 'sph2tan':   # box_formator.py:98-106: w = 2R tan(alpha / 2), 2R = img_w / pi
+            two_r = f(1024 / np.pi)
+            w = two_r * np.tan((x[:, 2] * f(np.pi / 180)) / f(2)).astype(f)
+            h = two_r * np.tan((x[:, 3] * f(np.pi / 180)) / f(2)).astype(f)
+        else:
+            assert box_formator == 'sph2pix'
+            w, h = (x[:, 2] / f(360)) * f(1024), (x[:, 3] / f(180)) * f(512)
+        return np.stack([(x[:, 0] / f(360)) * f(1024), (x[:, 1] / f(180)) * f(512), w, h], axis=1).astype(f)
     pa, pb = pix(a), pix(b)
     if dim == 4:
         def xyxy(p):

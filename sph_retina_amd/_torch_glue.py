@@ -8,8 +8,10 @@ from . import _lib
 
 import os
 
-_VARIANT_CODES = {'standard': 0, 'efficient': 1, 'legacy': 2, 'sph_iou': 3, 'fov_iou': 4, 'unbiased': 5, 'naive': 6}
+_VARIANT_CODES = {'standard': 0, 'efficient': 1, 'legacy': 2, 'sph_iou': 3, 'fov_iou': 4, 'unbiased': 5, 'naive': 6,
+                  'naive_tan': 6 | 0x400}   # naive_tan: naive IoU with Sph2PlanarBoxTransform('sph2tan')
 FLAG_REFERENCE_ORDER = 0x100
+FLAG_NAIVE_TAN = 0x400   # naive variant: Sph2PlanarBoxTransform('sph2tan') instead of 'sph2pix'
 _ARITHMETIC = os.environ.get('SPH2POB_ARITHMETIC', 'fast')
 if _ARITHMETIC not in ('fast', 'robust', 'reference'):
     raise ValueError(f"SPH2POB_ARITHMETIC must be 'fast', 'robust' or 'reference', got {_ARITHMETIC!r}")

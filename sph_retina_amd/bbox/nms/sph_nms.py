@@ -35,7 +35,7 @@ def _variant_of(iou_calculator):
         raise TypeError(f'iou_calculator must be a name or one of the sph IoU functions, got {type(iou_calculator).__name__}')
     if name in _CALCULATORS:
         return _CALCULATORS[name]
-    if name in _CALCULATORS.values():   # already a variant name ('efficient', ...): SphNMS hands these over
+    if name in _CALCULATORS.values() or name == 'naive_tan':   # already a variant name ('efficient', ...): SphNMS hands these over
         return name
     raise TypeError(f'Not supported iou_calculator: {name!r} (accepted: {sorted(_CALCULATORS)})')
 
@@ -97,7 +97,7 @@ def _fused_nms(boxes, scores, idxs, iou_threshold, max_num, variant):
 def _pairwise_fn(variant):
     from ...iou import sph_iou_api as A
     return {'efficient': A.sph2pob_efficient_iou, 'standard': A.sph2pob_standard_iou, 'unbiased': A.unbiased_iou,
-            'naive': A.naive_iou}[variant]
+            'naive': A.naive_iou, 'naive_tan': lambda a, b: A.naive_iou(a, b, box_formator='sph2tan')}[variant]
 
 
 def _nms_one_class_chunked(boxes_sorted, iou_threshold, variant, chunk=16384):
@@ -217,8 +217,7 @@ class PlanarNMS:
     result in descending score order, `max_num`) — parity unpinned."""
 
     def __init__(self, box_formator='sph2pix'):
-        if box_formator != 'sph2pix':
-            raise NotImplementedError("PlanarNMS: only box_formator='sph2pix' is served by sph_retina_amd")
+        assert box_formator in ['sph2pix', 'sph2tan']   # Sph2PlanarBoxTransform.__init__ (box_formator.py:163)
         self.box_formator = box_formator
 
     def __call__(self, boxes, scores, idxs, nms_cfg, class_agnostic=True):
@@ -226,4 +225,4 @@ class PlanarNMS:
         class_agnostic = nms_cfg_.pop('class_agnostic', class_agnostic)
         if class_agnostic:
             idxs = torch.zeros_like(idxs)
-        return sph_batched_nms(boxes, scores, idxs, nms_cfg_, 'naive', class_agnostic)
+        return sph_batched_nms(boxes, scores, idxs, nms_cfg_, 'naive' if self.box_formator == 'sph2pix' else 'naive_tan', class_agnostic)

@@ -535,11 +535,20 @@ SPH_DEV float approx_iou(const float (&g_)[5], const float (&p_)[5]) {
 // The planar stage has no jitter in front of it here, so exactly parallel rectangles (equal gamma: every
 // BFoV-like detection) are intersected as axis-aligned boxes in their common frame instead of through the
 // edge-crossing integral, which needs transversal edges.
+// `tan_form`: Sph2PlanarBoxTransform('sph2tan') (box_formator.py:98-106): w = 2R tan(alpha / 2), h = 2R tan(beta / 2) with
+// 2R = img_w / pi, instead of the 'sph2pix' proportions (:76-83)
 template <int DIM>
-SPH_DEV float naive_iou(const float (&b1)[5], const float (&b2)[5]) {
+SPH_DEV float naive_iou(const float (&b1)[5], const float (&b2)[5], bool tan_form = false) {
     const float W = 1024.0f, H = 512.0f;
-    const float xa = (b1[0] / 360.0f) * W, ya = (b1[1] / 180.0f) * H, wa = (b1[2] / 360.0f) * W, ha = (b1[3] / 180.0f) * H;
-    const float xb = (b2[0] / 360.0f) * W, yb = (b2[1] / 180.0f) * H, wb = (b2[2] / 360.0f) * W, hb = (b2[3] / 180.0f) * H;
+    const float xa = (b1[0] / 360.0f) * W, ya = (b1[1] / 180.0f) * H, xb = (b2[0] / 360.0f) * W, yb = (b2[1] / 180.0f) * H;
+    float wa, ha, wb, hb;
+    if (tan_form) {
+        const float twoR = (float)(1024.0 / 3.141592653589793);
+        wa = twoR * tanf((b1[2] * kDeg2Rad) / 2.0f); ha = twoR * tanf((b1[3] * kDeg2Rad) / 2.0f);
+        wb = twoR * tanf((b2[2] * kDeg2Rad) / 2.0f); hb = twoR * tanf((b2[3] * kDeg2Rad) / 2.0f);
+    } else {
+        wa = (b1[2] / 360.0f) * W; ha = (b1[3] / 180.0f) * H; wb = (b2[2] / 360.0f) * W; hb = (b2[3] / 180.0f) * H;
+    }
     if (DIM == 4) {  // xywh2xyxy (box_formator.py:25-31) + bbox_overlaps(mode='iou', aligned, offset=0)
         const float ax1 = xa - wa / 2.0f, ay1 = ya - ha / 2.0f, ax2 = xa + wa / 2.0f, ay2 = ya + ha / 2.0f;
         const float bx1 = xb - wb / 2.0f, by1 = yb - hb / 2.0f, bx2 = xb + wb / 2.0f, by2 = yb + hb / 2.0f;

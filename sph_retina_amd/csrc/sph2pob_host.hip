@@ -68,7 +68,7 @@ inline void load_box(const float* p, int64_t i, float (&b)[5]) {
 template <int V, int DIM>
 inline float pair_iou_any(const float (&x)[5], const float (&y)[5], bool fast, int mode, int edge, int angle) {
     if constexpr (V == VARIANT_UNBIASED) return fast ? unbiased_pair_iou<DIM, false>(x, y) : unbiased_pair_iou<DIM, true>(x, y);
-    else if constexpr (V == VARIANT_NAIVE) return naive_iou<DIM>(x, y);
+    else if constexpr (V == VARIANT_NAIVE) return naive_iou<DIM>(x, y, edge == EDGE_TANGENT);
     else if constexpr (V < 2) return (fast && angle == ANGLE_EQUATOR) ? pair_iou_fast<V, DIM>(x, y, mode, edge) : pair_iou<V, DIM>(x, y, mode, edge, angle);
     else return pair_iou<V, DIM>(x, y, mode, edge, angle);
 }
@@ -90,7 +90,8 @@ int dispatch(int variant_flags, int box_dim, F&& f) {
 
 int check_common(int box_dim, int variant_flags, int edge, int angle) {
     const int variant = variant_flags & 0xff;
-    if (variant_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER | SPH2POB_FLAG_ROBUST_PARALLEL)) return SPH2POB_ERR_OPTION;
+    if (variant_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER | SPH2POB_FLAG_ROBUST_PARALLEL | SPH2POB_FLAG_NAIVE_TAN)) return SPH2POB_ERR_OPTION;
+    if ((variant_flags & SPH2POB_FLAG_NAIVE_TAN) && variant != SPH2POB_VARIANT_NAIVE) return SPH2POB_ERR_OPTION;
     if (box_dim != 4 && box_dim != 5) return SPH2POB_ERR_DIM;
     if (variant < 0 || variant > SPH2POB_VARIANT_NAIVE || edge < 0 || edge > 2 || angle < 0 || angle > 1) return SPH2POB_ERR_OPTION;
     if (variant >= SPH2POB_VARIANT_LEGACY && variant <= SPH2POB_VARIANT_FOV_IOU && box_dim == 5) return SPH2POB_ERR_DIM;
@@ -211,7 +212,7 @@ double loss_pass_sel(int box_dim, bool fast, A... a) {
 
 // greedy NMS per class segment (sph2pob_nms_segmented_f32)
 struct NmsRun {
-    const float* boxes; const int64_t* cls; int64_t k; float thr; unsigned char* keep; bool fast = true;
+    const float* boxes; const int64_t* cls; int64_t k; float thr; unsigned char* keep; int edge; bool fast = true;
     template <int V, int D> int run() {
         if constexpr (V == 2 || V == 3 || V == 4) return SPH2POB_ERR_OPTION;
         else {
@@ -234,7 +235,7 @@ struct NmsRun {
                             if (removed[(size_t)(j - a)]) continue;
                             float y[5];
                             load_box<D>(boxes, j, y);
-                            if (pair_iou_any<V, D>(x, y, fast, MODE_IOU, EDGE_ARC, ANGLE_EQUATOR) > thr) removed[(size_t)(j - a)] = 1;
+                            if (pair_iou_any<V, D>(x, y, fast, MODE_IOU, edge, ANGLE_EQUATOR) > thr) removed[(size_t)(j - a)] = 1;
                         }
                     }
                 }
@@ -259,6 +260,7 @@ int sph2pob_iou_aligned_f32_cpu(const float* b1, const float* b2, float* out, in
     if (n < 0 || n > kMaxElems) return SPH2POB_ERR_SIZE;
     if (n == 0) return SPH2POB_OK;
     if (!b1 || !b2 || !out) return SPH2POB_ERR_NULL;
+    if (variant & SPH2POB_FLAG_NAIVE_TAN) edge = SPH2POB_EDGE_TANGENT;
     return dispatch(variant, box_dim, Aligned{b1, b2, out, n, mode, edge, angle});
 }
 
@@ -270,6 +272,7 @@ int sph2pob_iou_pairwise_f32_cpu(const float* b1, int64_t m, const float* b2, in
     if (m < 0 || n < 0 || n > kMaxElems || m > kMaxElems) return SPH2POB_ERR_SIZE;
     if (m == 0 || n == 0) return SPH2POB_OK;
     if (!b1 || !b2 || !out) return SPH2POB_ERR_NULL;
+    if (variant & SPH2POB_FLAG_NAIVE_TAN) edge = SPH2POB_EDGE_TANGENT;
     return dispatch(variant, box_dim, Pairwise{b1, m, b2, n, out, mode, edge, angle});
 }
 
@@ -436,7 +439,8 @@ int sph2pob_nms_segmented_f32_cpu(const float* boxes_sorted, const int64_t* cls_
                                   float iou_threshold, int64_t max_segment, void* workspace, unsigned char* keep, void*) {
     (void)max_segment; (void)workspace;   // no suppression matrix on the host: no per-class limit either
     const int variant = variant_flags & 0xff;
-    if (variant_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER | SPH2POB_FLAG_ROBUST_PARALLEL)) return SPH2POB_ERR_OPTION;
+    if (variant_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER | SPH2POB_FLAG_ROBUST_PARALLEL | SPH2POB_FLAG_NAIVE_TAN)) return SPH2POB_ERR_OPTION;
+    if ((variant_flags & SPH2POB_FLAG_NAIVE_TAN) && variant != SPH2POB_VARIANT_NAIVE) return SPH2POB_ERR_OPTION;
     if (box_dim != 4 && box_dim != 5) return SPH2POB_ERR_DIM;
     if (variant != SPH2POB_VARIANT_STANDARD && variant != SPH2POB_VARIANT_EFFICIENT && variant != SPH2POB_VARIANT_UNBIASED &&
         variant != SPH2POB_VARIANT_NAIVE)
@@ -444,7 +448,8 @@ int sph2pob_nms_segmented_f32_cpu(const float* boxes_sorted, const int64_t* cls_
     if (k < 0) return SPH2POB_ERR_SIZE;
     if (k == 0) return SPH2POB_OK;
     if (!boxes_sorted || !keep) return SPH2POB_ERR_NULL;
-    return dispatch(variant_flags, box_dim, NmsRun{boxes_sorted, cls_sorted, k, iou_threshold, keep});
+    return dispatch(variant_flags, box_dim, NmsRun{boxes_sorted, cls_sorted, k, iou_threshold, keep,
+                                                   (variant_flags & SPH2POB_FLAG_NAIVE_TAN) ? (int)EDGE_TANGENT : (int)EDGE_ARC});
 }
 int sph2pob_nms_f32_cpu(const float* boxes_sorted, const int64_t* cls_sorted, int64_t k, int box_dim, int variant_flags, float iou_threshold,
                         void* workspace, unsigned char* keep, void* stream) {

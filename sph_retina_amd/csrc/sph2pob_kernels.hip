@@ -60,7 +60,7 @@ __device__ __forceinline__ void load_box(const float* __restrict__ p, int64_t i,
 template <int VARIANT, int DIM, bool FAST>
 __device__ __forceinline__ float pair_iou_sel(const float (&x)[5], const float (&y)[5], int mode, int edge, int angle) {
     if constexpr (VARIANT == VARIANT_UNBIASED) return unbiased_pair_iou<DIM, !FAST>(x, y);
-    else if constexpr (VARIANT == VARIANT_NAIVE) return naive_iou<DIM>(x, y);
+    else if constexpr (VARIANT == VARIANT_NAIVE) return naive_iou<DIM>(x, y, edge == EDGE_TANGENT);   // (edge carries SPH2POB_FLAG_NAIVE_TAN)
     else if constexpr (FAST) return pair_iou_fast<VARIANT, DIM>(x, y, mode, edge);
     else return pair_iou<VARIANT, DIM>(x, y, mode, edge, angle);
 }
@@ -877,7 +877,7 @@ __device__ __forceinline__ void wave_class_segment(const int64_t* __restrict__ c
 template <int VARIANT, int DIM, bool FAST>
 __global__ __launch_bounds__(kBlock) void nms_mask_kernel(const float* __restrict__ boxes,
                                                          const int64_t* __restrict__ cls, int64_t k, int words,
-                                                         float thr, unsigned long long* __restrict__ mask) {
+                                                         float thr, unsigned long long* __restrict__ mask, int edge) {
     // one wave per row i: only the words that hold later columns of row i's own class segment are evaluated.
     // Row layout: `words` u64 per row, word r of row i covers columns 64 * ((seg_start >> 6) + r) ...: indices are
     // relative to the row's class segment, so the matrix is k x (largest segment / 64 + 2) instead of k x k / 64.
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(kBlock) void nms_mask_kernel(const float* __restric
         if (j > i && j < seg_end) {
             float y[5];
             load_box<DIM>(boxes, j, y);
-            hit = pair_iou_sel<VARIANT, DIM, FAST>(x, y, MODE_IOU, EDGE_ARC, ANGLE_EQUATOR) > thr;
+            hit = pair_iou_sel<VARIANT, DIM, FAST>(x, y, MODE_IOU, edge, ANGLE_EQUATOR) > thr;
         }
         unsigned long long bits = __builtin_amdgcn_ballot_w64(hit);
         if (lane == 0) row[r] = bits;
@@ -1566,7 +1566,8 @@ __global__ __launch_bounds__(kBlock) void transform_bwd_dual_kernel(const float*
 
 int check_common(int box_dim, int variant_flags, int edge, int angle) {
     const int variant = variant_flags & 0xff;
-    if (variant_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER | SPH2POB_FLAG_ROBUST_PARALLEL)) return SPH2POB_ERR_OPTION;
+    if (variant_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER | SPH2POB_FLAG_ROBUST_PARALLEL | SPH2POB_FLAG_NAIVE_TAN)) return SPH2POB_ERR_OPTION;
+    if ((variant_flags & SPH2POB_FLAG_NAIVE_TAN) && variant != SPH2POB_VARIANT_NAIVE) return SPH2POB_ERR_OPTION;
     if (box_dim != 4 && box_dim != 5) return SPH2POB_ERR_DIM;
     if (variant < 0 || variant > SPH2POB_VARIANT_NAIVE || edge < 0 || edge > 2 || angle < 0 || angle > 1) return SPH2POB_ERR_OPTION;
     if (variant >= SPH2POB_VARIANT_LEGACY && variant <= SPH2POB_VARIANT_FOV_IOU && box_dim == 5)
@@ -1779,6 +1780,7 @@ int sph2pob_iou_aligned_f32(const float* b1, const float* b2, float* out, int64_
     if (n < 0 || n > kMaxElems) return SPH2POB_ERR_SIZE;
     if (n == 0) return SPH2POB_OK;
     if (!b1 || !b2 || !out) return SPH2POB_ERR_NULL;
+    if (variant & SPH2POB_FLAG_NAIVE_TAN) edge = SPH2POB_EDGE_TANGENT;
     return dispatch(variant, box_dim, AlignedLaunch{b1, b2, out, n, mode, edge, angle, (hipStream_t)stream});
 }
 
@@ -1790,6 +1792,7 @@ int sph2pob_iou_pairwise_f32(const float* b1, int64_t m, const float* b2, int64_
     if (m < 0 || n < 0 || n > kMaxElems || m > kMaxElems) return SPH2POB_ERR_SIZE;
     if (m == 0 || n == 0) return SPH2POB_OK;
     if (!b1 || !b2 || !out) return SPH2POB_ERR_NULL;
+    if (variant & SPH2POB_FLAG_NAIVE_TAN) edge = SPH2POB_EDGE_TANGENT;
     return dispatch(variant, box_dim, PairwiseLaunch{b1, m, b2, n, out, mode, edge, angle, (hipStream_t)stream});
 }
 
@@ -1983,7 +1986,8 @@ int64_t sph2pob_nms_segmented_workspace_bytes(int64_t k, int64_t max_segment) {
 static int nms_check_options(int box_dim, int variant_flags) {
     const int variant = variant_flags & 0xff;
     // SPH2POB_FLAG_ROBUST_PARALLEL is accepted and has no effect here (a near-parallel pair is far above any threshold)
-    if (variant_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER | SPH2POB_FLAG_ROBUST_PARALLEL)) return SPH2POB_ERR_OPTION;
+    if (variant_flags & ~(0xff | SPH2POB_FLAG_REFERENCE_ORDER | SPH2POB_FLAG_ROBUST_PARALLEL | SPH2POB_FLAG_NAIVE_TAN)) return SPH2POB_ERR_OPTION;
+    if ((variant_flags & SPH2POB_FLAG_NAIVE_TAN) && variant != SPH2POB_VARIANT_NAIVE) return SPH2POB_ERR_OPTION;
     if (box_dim != 4 && box_dim != 5) return SPH2POB_ERR_DIM;
     if (variant != SPH2POB_VARIANT_STANDARD && variant != SPH2POB_VARIANT_EFFICIENT && variant != SPH2POB_VARIANT_UNBIASED &&
         variant != SPH2POB_VARIANT_NAIVE)
@@ -1998,7 +2002,8 @@ static int nms_mask_and_sweep(const float* boxes_sorted, const int64_t* cls_sort
     const int wpb = kBlock / 64;
     dim3 grid((unsigned)((k + wpb - 1) / wpb));
 #define SPH_NMS_LAUNCH(V, D, F) \
-    hipLaunchKernelGGL((nms_mask_kernel<V, D, F>), grid, dim3(kBlock), 0, s, boxes_sorted, cls_sorted, k, words, iou_threshold, mask)
+    hipLaunchKernelGGL((nms_mask_kernel<V, D, F>), grid, dim3(kBlock), 0, s, boxes_sorted, cls_sorted, k, words, iou_threshold, mask, \
+                       (variant_flags & SPH2POB_FLAG_NAIVE_TAN) ? (int)EDGE_TANGENT : (int)EDGE_ARC)
 #define SPH_NMS_COMPACT(V, D) \
     hipLaunchKernelGGL((nms_mask_compact_kernel<V, D>), grid, dim3(kBlock), 0, s, boxes_sorted, cls_sorted, k, words, iou_threshold, mask)
     const bool compact = fast && !g_no_compact && k < ((int64_t)1 << 31) - 64 &&

@@ -83,11 +83,12 @@ def unbiased_iou(bboxes1, bboxes2, mode='iou', is_aligned=False):
 
 def naive_iou(bboxes1, bboxes2, mode='iou', is_aligned=False, box_formator='sph2pix'):
     """Naive IoU — planar IoU of the boxes drawn in ERP pixels (reference sph_iou_api.py:179-197): axis-aligned for
-    BFoV (mmcv bbox_overlaps), rotated for RBFoV (mmcv box_iou_rotated); no jitter, no clamp."""
+    BFoV (mmcv bbox_overlaps), rotated for RBFoV (mmcv box_iou_rotated); no jitter, no clamp.  `box_formator`: 'sph2pix'
+    (proportional widths) or 'sph2tan' (w = 2R tan(alpha / 2): box_formator.py:98-106)."""
     assert mode in ['iou']
-    if box_formator != 'sph2pix':  # 'sph2tan' is accepted by Sph2PlanarBoxTransform; no caller in the reference uses it
-        raise NotImplementedError("naive_iou: only box_formator='sph2pix' is served by sph_retina_amd")
-    return _sph2pob_iou_auxiliary(bboxes1, bboxes2, 'naive', 'iou', is_aligned, 'common', 'arc', 'equator')
+    assert box_formator in ['sph2pix', 'sph2tan']   # Sph2PlanarBoxTransform.__init__ (box_formator.py:163)
+    return _sph2pob_iou_auxiliary(bboxes1, bboxes2, 'naive' if box_formator == 'sph2pix' else 'naive_tan', 'iou', is_aligned, 'common',
+                                  'arc', 'equator')
 
 
 def sph2pob_legacy_iou(bboxes1, bboxes2, mode='iou', is_aligned=False, calculator='common', rbb_edge='arc'):

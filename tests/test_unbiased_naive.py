@@ -257,3 +257,55 @@ def test_gpu_reference_sample_pairs_other_backends():
     assert np.abs(I.fov_iou(t1, t2, is_aligned=True).cpu().numpy() - g['fov']).max() < 1e-6
     # input immutability (tests/test_all_ious.py:322-332)
     assert torch.equal(t1, cu(g['b1'])) and torch.equal(t2, cu(g['b2']))
+
+
+# ---- round 3: naive IoU with both planar box formators (Sph2PlanarBoxTransform 'sph2pix' | 'sph2tan') ----
+@pytest.mark.parametrize('formator', ['sph2pix', 'sph2tan'])
+def test_naive_rbfov_both_formators_vs_reference_fixture_cpu(oracle, formator):
+    """tests/golden/naive.npz: the reference's naive_iou on RBFoV pairs (sph_iou_api.py:179-197, box_formator.py:76-106) through
+    its vendored planar IoU.  The oracle restatement and the product's host twin (CPU tensors) against it; the BFoV branch
+    needs mmcv.ops.bbox_overlaps (absent): parity unpinned, checked against the restatement only."""
+    from sph_retina_amd.iou import naive_iou
+    g = load_golden('naive')
+    ref, ref64 = g['iou_' + formator], g['iou64_' + formator]
+    o = oracle.naive_iou(g['b1'], g['b2'], planar='diff', box_formator=formator)
+    assert np.abs(o - ref).max() < 1e-5 and np.abs(o - ref).mean() < 3e-7
+    got = naive_iou(torch.from_numpy(g['b1']), torch.from_numpy(g['b2']), is_aligned=True, box_formator=formator).numpy()
+    assert np.abs(got - ref64).max() < 5e-6, np.abs(got - ref64).max()     # the kernel's rotated stage runs in double
+    assert np.abs(got - ref).max() < 2.5e-5
+    b4 = g['b1'][:, :4], g['b2'][:, :4]
+    got4 = naive_iou(torch.from_numpy(b4[0].copy()), torch.from_numpy(b4[1].copy()), is_aligned=True, box_formator=formator).numpy()
+    assert np.abs(got4 - oracle.naive_iou(b4[0], b4[1], box_formator=formator)).max() < 5e-6    # (tanf of the host libm vs numpy's)
+    with pytest.raises(AssertionError):
+        naive_iou(torch.from_numpy(g['b1']), torch.from_numpy(g['b2']), box_formator='sph2kent')
+    if formator == 'sph2tan':
+        assert np.abs(ref - g['iou_sph2pix']).max() > 1e-2      # the two formators really differ
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('formator', ['sph2pix', 'sph2tan'])
+def test_gpu_naive_both_formators_and_planar_nms(oracle, formator):
+    from sph_retina_amd.iou import naive_iou
+    from sph_retina_amd.bbox.nms import PlanarNMS
+    g = load_golden('naive')
+    got = naive_iou(cu(g['b1']), cu(g['b2']), is_aligned=True, box_formator=formator).cpu().numpy()
+    assert np.abs(got - g['iou64_' + formator]).max() < 5e-6
+    pw = naive_iou(cu(g['b1'][:40]), cu(g['b2'][:70]), box_formator=formator).cpu().numpy()
+    assert np.abs(pw - oracle.naive_iou(g['b1'][:40], g['b2'][:70], is_aligned=False, planar='exact', box_formator=formator)).max() < 5e-6
+    host = naive_iou(torch.from_numpy(g['b1']), torch.from_numpy(g['b2']), is_aligned=True, box_formator=formator).numpy()
+    assert np.abs(host - got).max() < 2e-6
+    # PlanarNMS(box_formator) = naive-IoU NMS with that formator (sphdet/bbox/nms/planar_nms.py:7-19)
+    rng = np.random.default_rng(3)
+    b = g['b1'][:600, :4].copy()
+    b[:, :2] = np.array([180, 90], np.float32) + rng.standard_normal((600, 2)).astype(np.float32) * 12
+    s = rng.random(600).astype(np.float32)
+    dets, keep = PlanarNMS(formator)(cu(b), cu(s), cu(np.zeros(600, np.int64)), dict(iou_threshold=0.5))
+    iou = oracle.naive_iou(b, b, is_aligned=False, box_formator=formator)
+    order = np.argsort(-s, kind='stable')
+    want, alive = [], np.ones(600, bool)
+    for i in order:
+        if alive[i]:
+            want.append(i)
+            alive &= ~(iou[i] > 0.5)
+            alive[i] = False
+    assert keep.tolist() == want
