@@ -155,8 +155,9 @@ def test_planar_nms_is_naive_iou_nms_class_agnostic_by_default(N, oracle):
     d_pc, k_pc = N.PlanarNMS()(cu(b), cu(scores), cu(idxs), dict(cfg, class_agnostic=False))
     rd, rk = oracle.batched_nms(b, scores, idxs, 0.5, variant='naive')
     assert np.array_equal(k_pc.cpu().numpy(), rk) and len(rk) >= len(k_ag)
-    with pytest.raises(NotImplementedError):
-        N.PlanarNMS('sph2tan')
+    assert N.PlanarNMS('sph2tan').box_formator == 'sph2tan'      # served since round 3 (tests/test_unbiased_naive.py)
+    with pytest.raises(AssertionError):
+        N.PlanarNMS('sph2kent')
 
 
 def test_long_single_class_segment_through_the_pipelined_sweep(N, oracle):
