@@ -95,7 +95,7 @@ def workloads(args, torch, G):
     st = G.raw_stream_of(torch.device('cuda', 0))
     if args.workload == 'aligned':
         from bench import make_boxes
-        variant = {'standard': 0, 'efficient': 1, 'legacy': 2}[args.variant] | (0x100 if args.reference_order else 0)
+        variant = {'standard': 0, 'efficient': 1, 'legacy': 2, 'sph_iou': 3, 'fov_iou': 4, 'unbiased': 5, 'naive': 6}[args.variant] | (0x100 if args.reference_order else 0)
         for n in [int(x) for x in args.pairs.split(',')]:
             if args.dim == 4:
                 b1, b2 = make_boxes(n, 0, 'cuda'), make_boxes(n, 1, 'cuda')
