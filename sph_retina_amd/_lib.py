@@ -24,8 +24,9 @@ HOST_FLAGS = ['--offload-arch=gfx950', '--cuda-host-only', '-O2', '-std=c++17', 
 HOST_TWINS = ['sph2pob_iou_aligned_f32', 'sph2pob_iou_pairwise_f32', 'sph2pob_planar_iou_f32', 'sph2pob_transform_f32',
               'sph2pob_transform_bwd_f32', 'sph2pob_transform_bwd_general_f32', 'sph2pob_loss_fwd_f32', 'sph2pob_loss_bwd_f32',
               'sph2pob_loss_fwd_sum_f32', 'sph2pob_loss_fwd_grad_f32', 'sph2pob_loss_grad_scale_f32', 'sph2pob_sum_f32',
-              'sph2pob_nms_segmented_f32', 'sph2pob_nms_f32', 'sph2pob_assign_f32']
-HEADERS = ['sph2pob_device.hpp', 'sph2pob_loss.hpp', 'sph2pob_fast.hpp', 'sph2pob_unbiased.hpp', os.path.join('..', '..', 'include', 'sph2pob_hip.h')]
+              'sph2pob_nms_segmented_f32', 'sph2pob_nms_f32', 'sph2pob_assign_f32', 'sph2pob_coder_encode_f32',
+              'sph2pob_coder_decode_f32', 'sph2pob_coder_decode_bwd_f32', 'sph2pob_obb_l1_fwd_f32', 'sph2pob_obb_l1_bwd_f32']
+HEADERS = ['sph2pob_device.hpp', 'sph2pob_loss.hpp', 'sph2pob_fast.hpp', 'sph2pob_unbiased.hpp', 'sph2pob_coder.hpp', os.path.join('..', '..', 'include', 'sph2pob_hip.h')]
 # -fno-slp-vectorize: hipcc otherwise pairs scalar fp32 mul/add into v_pk_* (+ v_mov shuffles); packed fp32 issues at
 # half the rate of plain VALU on gfx950 (tools/ubench/valu_rate2.hip), measured 12 % slower on the dominant kernel
 # -amdgpu-kernarg-preload-count: gfx950 hands the first kernel arguments to a wave in SGPRs at launch instead of making

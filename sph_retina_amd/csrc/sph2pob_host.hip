@@ -23,6 +23,7 @@
 #include "sph2pob_loss.hpp"
 #include "sph2pob_fast.hpp"
 #include "sph2pob_unbiased.hpp"
+#include "sph2pob_coder.hpp"
 
 namespace {
 
@@ -508,6 +509,105 @@ int sph2pob_assign_f32_cpu(const float* ov, int64_t k, int64_t n, float pos_iou_
     }
     if (assigned_labels)
         for (int64_t j = 0; j < n; j++) assigned_labels[j] = assigned_gt_inds[j] > 0 ? gt_labels[assigned_gt_inds[j] - 1] : -1;
+    return SPH2POB_OK;
+}
+
+}  // extern "C"
+
+// ---- box coders and the OBB L1 loss body (sph2pob_coder.hpp: the rows the kernels of sph2pob_coder.hip compute) ----
+namespace {
+namespace C = sph2pob_coder;
+
+template <int DIM>
+void coder_encode_rows(const float* proposals, const float* gt, const C::Norm& nm, float* deltas, int64_t n) {
+    parallel_for(n, 1 << 14, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; i++) {
+            float d[5];
+            C::encode_one<DIM>(proposals + i * DIM, gt + i * DIM, nm, d);
+            for (int k = 0; k < DIM; k++) deltas[i * DIM + k] = d[k];
+        }
+    });
+}
+
+template <int DIM, bool BWD>
+void coder_decode_rows(const float* rois, const float* deltas, const float* grad_boxes, const C::Norm& nm, float* out, int64_t total,
+                       int num_classes, float max_ratio, int flags, float ctr_clamp) {
+    parallel_for(total, 1 << 14, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; i++) {
+            float p[5] = {0, 0, 0, 0, 0}, b[5], j[5];
+            const float* r = rois + (num_classes == 1 ? i : i / num_classes) * DIM;
+            for (int k = 0; k < DIM; k++) p[k] = r[k];
+            C::decode_one<DIM, BWD>(p, deltas + i * DIM, nm, max_ratio, flags, ctr_clamp, b, BWD ? j : nullptr);
+            for (int k = 0; k < DIM; k++) out[i * DIM + k] = BWD ? grad_boxes[i * DIM + k] * j[k] : b[k];
+        }
+    });
+}
+}  // namespace
+
+extern "C" {
+
+int sph2pob_coder_encode_f32_cpu(const float* proposals, const float* gt, const float* means_host, const float* stds_host,
+                                 float* deltas, int64_t n, int box_dim, void*) {
+    if (int rc = C::check_encode(proposals, gt, deltas, n, box_dim)) return rc;
+    if (n == 0) return 0;
+    const C::Norm nm = C::make_norm(means_host, stds_host, box_dim);
+    if (box_dim == 4) coder_encode_rows<4>(proposals, gt, nm, deltas, n);
+    else coder_encode_rows<5>(proposals, gt, nm, deltas, n);
+    return SPH2POB_OK;
+}
+
+int sph2pob_coder_decode_f32_cpu(const float* rois, const float* deltas, const float* means_host, const float* stds_host,
+                                 float* boxes, int64_t n, int num_classes, int box_dim, float max_ratio, int flags,
+                                 float ctr_clamp, void*) {
+    if (int rc = C::check_decode(rois, deltas, deltas, boxes, n, num_classes, box_dim, max_ratio, flags)) return rc;
+    if (n == 0) return 0;
+    const C::Norm nm = C::make_norm(means_host, stds_host, box_dim);
+    if (box_dim == 4) coder_decode_rows<4, false>(rois, deltas, nullptr, nm, boxes, n * num_classes, num_classes, max_ratio, flags, ctr_clamp);
+    else coder_decode_rows<5, false>(rois, deltas, nullptr, nm, boxes, n * num_classes, num_classes, max_ratio, flags, ctr_clamp);
+    return SPH2POB_OK;
+}
+
+int sph2pob_coder_decode_bwd_f32_cpu(const float* rois, const float* deltas, const float* grad_boxes, const float* means_host,
+                                     const float* stds_host, float* grad_deltas, int64_t n, int num_classes, int box_dim,
+                                     float max_ratio, int flags, float ctr_clamp, void*) {
+    if (int rc = C::check_decode(rois, deltas, grad_boxes, grad_deltas, n, num_classes, box_dim, max_ratio, flags)) return rc;
+    if (n == 0) return 0;
+    const C::Norm nm = C::make_norm(means_host, stds_host, box_dim);
+    if (box_dim == 4) coder_decode_rows<4, true>(rois, deltas, grad_boxes, nm, grad_deltas, n * num_classes, num_classes, max_ratio, flags, ctr_clamp);
+    else coder_decode_rows<5, true>(rois, deltas, grad_boxes, nm, grad_deltas, n * num_classes, num_classes, max_ratio, flags, ctr_clamp);
+    return SPH2POB_OK;
+}
+
+int sph2pob_obb_l1_fwd_f32_cpu(const float* planar_pred, const float* planar_target, const float* weight, float scale, float* loss,
+                               int64_t n, int flags, void*) {
+    if (int rc = C::check_l1(planar_pred, planar_target, planar_pred, loss, n, flags)) return rc;
+    if (n == 0) return 0;
+    parallel_for(n, 1 << 14, [&](int64_t lo, int64_t hi) {
+        const float ones[5] = {1.0f, 1.0f, 1.0f, 1.0f, 1.0f};
+        for (int64_t i = lo; i < hi; i++) {
+            float d[5];
+            C::l1_fwd_one(planar_pred + i * 5, planar_target + i * 5, weight ? weight + i * 5 : ones, scale, flags, d);
+            for (int k = 0; k < 5; k++) loss[i * 5 + k] = d[k];
+        }
+    });
+    return SPH2POB_OK;
+}
+
+int sph2pob_obb_l1_bwd_f32_cpu(const float* planar_pred, const float* planar_target, const float* weight, const float* grad_loss,
+                               float scale, float* grad_pred, float* grad_target, int64_t n, int flags, void*) {
+    if (int rc = C::check_l1(planar_pred, planar_target, grad_loss, grad_pred, n, flags)) return rc;
+    if (n == 0) return 0;
+    parallel_for(n, 1 << 14, [&](int64_t lo, int64_t hi) {
+        const float ones[5] = {1.0f, 1.0f, 1.0f, 1.0f, 1.0f};
+        for (int64_t i = lo; i < hi; i++) {
+            float u[5], ga[5], gb[5];
+            for (int k = 0; k < 5; k++) u[k] = grad_loss[i * 5 + k];
+            C::l1_bwd_one(planar_pred + i * 5, planar_target + i * 5, weight ? weight + i * 5 : ones, u, scale, flags, ga, gb);
+            for (int k = 0; k < 5; k++) grad_pred[i * 5 + k] = ga[k];
+            if (grad_target)
+                for (int k = 0; k < 5; k++) grad_target[i * 5 + k] = gb[k];
+        }
+    });
     return SPH2POB_OK;
 }
 

@@ -41,28 +41,45 @@ def test_restatement_matches_reference_outputs(oracle, dim, cls):
     assert (g[k + 'gdeltas'] == 0).any() and (g[k + 'dec'][:, 2:4] >= 179.9).any()
 
 
-def test_coder_registry_and_cpu_tensors_fail_loudly():
+def test_coder_registry_and_asserts():
     import sph_retina_amd as S
     from sph_retina_amd.registry import BBOX_CODERS, build_bbox_coder
     assert 'DeltaXYWHSphBBoxCoder' in BBOX_CODERS or hasattr(BBOX_CODERS, 'get')
     coder = build_bbox_coder(dict(type='DeltaXYWHASphBBoxCoder', target_stds=(1., 1., 1., 1., 1.)))
     assert isinstance(coder, S.DeltaXYWHASphBBoxCoder) and coder.box_dim == 5
-    with pytest.raises(RuntimeError, match='no CPU fallback|MI355X'):
-        coder.encode(torch.zeros(2, 5), torch.ones(2, 5))
+    enc = coder.encode(torch.ones(2, 5), torch.ones(2, 5))          # CPU tensors: the product's host twin
+    assert enc.device.type == 'cpu' and torch.equal(enc, torch.zeros(2, 5))
     with pytest.raises(AssertionError):
         S.DeltaXYWHSphBBoxCoder().encode(torch.zeros(2, 5), torch.ones(2, 5))
     empty = S.DeltaXYWHSphBBoxCoder().decode(torch.zeros(0, 4), torch.zeros(0, 4))
     assert empty.shape == (0, 4)
 
 
-def cu(a):
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+def cu(a, device='cuda'):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('dim,cls', CASES)
 def test_gpu_coder_matches_reference_outputs(dim, cls):
+    coder_fixture_on(dim, cls, 'cuda')
+
+
+@pytest.mark.parametrize('dim,cls', CASES)
+def test_cpu_twin_coder_matches_reference_outputs(dim, cls):
+    """CPU tensors (the reference's coders are plain torch and run wherever the boxes live): libsph2pob_host.so computes the
+    rows with the very functions of csrc/sph2pob_coder.hpp the kernels run."""
+    coder_fixture_on(dim, cls, 'cpu')
+
+
+def coder_fixture_on(dim, cls, device):
+    import functools
     import sph_retina_amd.bbox.coder as C
+    cu_dev = functools.partial(cu, device=device)
+    return _coder_fixture(C, cu_dev, dim, cls)
+
+
+def _coder_fixture(C, cu, dim, cls):
     g = load_golden('coder')
     k = f'd{dim}_'
     a, gt, m, s = cu(g[k + 'anchors']), cu(g[k + 'gts']), tuple(g[k + 'means']), tuple(g[k + 'stds'])

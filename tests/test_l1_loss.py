@@ -47,20 +47,30 @@ def test_l1_registry_and_asserts():
         Sph2PobL1Loss(angle_modifier='wrap')         # sph2pob_l1_loss.py:20
     with pytest.raises(AssertionError):
         loss(torch.zeros(2, 4), torch.zeros(2, 4), reduction_override='median')
-    with pytest.raises(RuntimeError):
-        loss(torch.rand(2, 4), torch.rand(2, 4))     # CPU tensors: no fallback
+    cpu = loss(torch.rand(2, 4) * 50 + 20, torch.rand(2, 4) * 50 + 20)     # CPU tensors: the product's host twins
+    assert cpu.device.type == 'cpu' and torch.isfinite(cpu)
     assert S.__version__
-
-
-def cu(a, grad=False):
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda().requires_grad_(grad)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('box', ['bfov', 'rbfov'])
 @pytest.mark.parametrize('name,cfg', CFGS)
 def test_gpu_l1_values_grads_reductions(box, name, cfg):
+    l1_fixture_on('cuda', box, name, cfg)
+
+
+@pytest.mark.parametrize('box', ['bfov', 'rbfov'])
+@pytest.mark.parametrize('name,cfg', CFGS)
+def test_cpu_twin_l1_values_grads_reductions(box, name, cfg):
+    """The same criteria on CPU tensors: transform + adjoint and the L1 rows from libsph2pob_host.so."""
+    l1_fixture_on('cpu', box, name, cfg)
+
+
+def l1_fixture_on(device, box, name, cfg):
     from sph_retina_amd.losses import Sph2PobL1Loss
+
+    def cu(a, grad=False):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device).requires_grad_(grad)
     g = load_golden('l1')
     k = f'{box}_{name}_'
     pred, target = cu(g[box + '_pred'], True), cu(g[box + '_target'], True)
