@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 LIB_DIR = os.path.join(_HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libsph2pob_hip.so')
 HOST_LIB_PATH = os.path.join(LIB_DIR, 'libsph2pob_host.so')
-SOURCES = ['sph2pob_kernels.hip', 'sph2pob_coder.hip']
+SOURCES = ['sph2pob_iou.hip', 'sph2pob_assign.hip', 'sph2pob_loss.hip', 'sph2pob_nms.hip', 'sph2pob_coder.hip']
 HOST_SOURCES = ['sph2pob_host.hip']
 HOST_FLAGS = ['--offload-arch=gfx950', '--cuda-host-only', '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-pthread']
 # the entry points that have a CPU twin `<name>_cpu` with the same signature (the stream argument is ignored)
@@ -26,7 +26,7 @@ HOST_TWINS = ['sph2pob_iou_aligned_f32', 'sph2pob_iou_pairwise_f32', 'sph2pob_pl
               'sph2pob_loss_fwd_sum_f32', 'sph2pob_loss_fwd_grad_f32', 'sph2pob_loss_grad_scale_f32', 'sph2pob_sum_f32',
               'sph2pob_nms_segmented_f32', 'sph2pob_nms_f32', 'sph2pob_assign_f32', 'sph2pob_coder_encode_f32',
               'sph2pob_coder_decode_f32', 'sph2pob_coder_decode_bwd_f32', 'sph2pob_obb_l1_fwd_f32', 'sph2pob_obb_l1_bwd_f32']
-HEADERS = ['sph2pob_device.hpp', 'sph2pob_loss.hpp', 'sph2pob_fast.hpp', 'sph2pob_unbiased.hpp', 'sph2pob_coder.hpp', os.path.join('..', '..', 'include', 'sph2pob_hip.h')]
+HEADERS = ['sph2pob_device.hpp', 'sph2pob_loss.hpp', 'sph2pob_fast.hpp', 'sph2pob_unbiased.hpp', 'sph2pob_coder.hpp', 'sph2pob_kernels_common.hpp', os.path.join('..', '..', 'include', 'sph2pob_hip.h')]
 # -fno-slp-vectorize: hipcc otherwise pairs scalar fp32 mul/add into v_pk_* (+ v_mov shuffles); packed fp32 issues at
 # half the rate of plain VALU on gfx950 (tools/ubench/valu_rate2.hip), measured 12 % slower on the dominant kernel
 # -amdgpu-kernarg-preload-count: gfx950 hands the first kernel arguments to a wave in SGPRs at launch instead of making
@@ -123,16 +123,46 @@ def _stale():
 
 
 def _compile(flags, sources, out, verbose):
+    """One hipcc -c per translation unit, in parallel, then one link.  Objects are kept under lib/obj/ and reused while they
+    are newer than their source and every header and were built with the same flags (an edit to one .hip recompiles one unit)."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
         raise Sph2PobLibraryError(f'hipcc not found: cannot build {os.path.basename(out)}')
     os.makedirs(LIB_DIR, exist_ok=True)
-    tmp = f'{out}.tmp.{os.getpid()}'   # built aside and renamed: other ranks / processes never see a partial file
-    cmd = [hipcc] + flags + ['-o', tmp] + [os.path.join(CSRC, s) for s in sources]
+    obj_dir = os.path.join(LIB_DIR, 'obj')
+    os.makedirs(obj_dir, exist_ok=True)
+    cflags = [f for f in flags if f != '-shared']
+    tag = hashlib.sha1(' '.join(cflags).encode()).hexdigest()[:10]
+    deps = [os.path.join(CSRC, h) for h in HEADERS]
+    newest_header = max(os.path.getmtime(d) for d in deps if os.path.exists(d))
+
+    def unit(src):
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(obj_dir, f'{os.path.splitext(src)[0]}.{tag}.o')
+        if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), newest_header):
+            return obj
+        tmp = f'{obj}.tmp.{os.getpid()}'
+        cmd = [hipcc] + cflags + ['-c', '-o', tmp, path]
+        if verbose:
+            print(' '.join(cmd))
+        try:
+            subprocess.check_call(cmd, cwd=CSRC)
+            os.replace(tmp, obj)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(sources), max(1, min(os.cpu_count() or 1, 8)))) as pool:
+        objs = list(pool.map(unit, sources))
+    tmp = f'{out}.tmp.{os.getpid()}'   # linked aside and renamed: other ranks / processes never see a partial file
+    link = [hipcc] + [f for f in flags if f.startswith('--offload-arch') or f in ('-shared', '-fPIC', '-pthread', '--cuda-host-only')] + ['-o', tmp] + objs
     if verbose:
-        print(' '.join(cmd))
+        print(' '.join(link))
     try:
-        subprocess.check_call(cmd, cwd=CSRC)
+        subprocess.check_call(link, cwd=CSRC)
         os.replace(tmp, out)
     finally:
         if os.path.exists(tmp):

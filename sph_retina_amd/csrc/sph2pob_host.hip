@@ -65,7 +65,7 @@ inline void load_box(const float* p, int64_t i, float (&b)[5]) {
     for (int k = 0; k < 5; k++) b[k] = k < DIM ? p[i * DIM + k] : 0.0f;
 }
 
-// the selection the kernels make (sph2pob_kernels.hip: pair_iou_sel and the launch rules of AlignedLaunch)
+// the selection the kernels make (sph2pob_kernels_common.hpp: pair_iou_sel; sph2pob_iou.hip: the launch rules of AlignedLaunch)
 template <int V, int DIM>
 inline float pair_iou_any(const float (&x)[5], const float (&y)[5], bool fast, int mode, int edge, int angle) {
     if constexpr (V == VARIANT_UNBIASED) return fast ? unbiased_pair_iou<DIM, false>(x, y) : unbiased_pair_iou<DIM, true>(x, y);
@@ -155,7 +155,7 @@ struct Transform {
 
 // ---- loss ----
 template <int DIM>
-inline float element_weight(const float* w, int wd, int64_t i) {   // sph2pob_kernels.hip: element_weight
+inline float element_weight(const float* w, int wd, int64_t i) {   // sph2pob_loss.hip: element_weight
     if (!w) return 1.0f;
     if (wd == 1) return w[i];
     float s = 0.0f;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static instruction mix of one kernel from hipcc's `-S` device assembly, per basic block.
 
-    hipcc --offload-arch=gfx950 -O3 ... --cuda-device-only -S -o k.s sph2pob_kernels.hip
+    hipcc --offload-arch=gfx950 -O3 ... --cuda-device-only -S -o k.s sph2pob_iou.hip   (or sph2pob_{assign,loss,nms}.hip)
     python tools/isa_mix.py k.s 'iou_aligned_compact_kernel<0, 4, true, false>' [--blocks]
 
 Cost weights (cycles per wave64 instruction with several waves per SIMD; tools/ubench/valu_rate*.hip and

@@ -74,6 +74,28 @@ def run():
         print(f'bursts {r0} -> {r1}: events slope {k:.3f} us per launch, fixed {e0 - k * r0:.1f} us; wall slope {kw:.3f}, fixed {w0 - kw * r0:.1f} us')
 
 
+def bracket():
+    """the contract's bracket at the driver's K = 20: synchronize, K launches, synchronize — where its fixed cost sits"""
+    torch, dev, stream, launch, keep = setup()
+    for _ in range(3000):
+        launch()
+    torch.cuda.synchronize(dev)
+    for K in (20, 100):
+        sub, tot = [], []
+        for _ in range(101):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(K):
+                launch()
+            t1 = time.perf_counter()
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter()
+            sub.append((t1 - t0) * 1e6)
+            tot.append((t2 - t0) * 1e6)
+        print(f'ROC_ACTIVE_WAIT_TIMEOUT={os.environ.get("ROC_ACTIVE_WAIT_TIMEOUT")}: K={K}: submission {statistics.median(sub):7.1f} us, '
+              f'bracket {statistics.median(tot):7.1f} us = {statistics.median(tot) / K:6.3f} per step (min {min(tot) / K:6.3f})', flush=True)
+
+
 def bursts():
     torch, dev, stream, launch, keep = setup()
     for _ in range(3000):
@@ -112,4 +134,4 @@ def read(path):
 
 if __name__ == '__main__':
     mode = sys.argv[1] if len(sys.argv) > 1 else 'run'
-    {'run': run, 'bursts': bursts}.get(mode, lambda: read(sys.argv[2]))()
+    {'run': run, 'bursts': bursts, 'bracket': bracket}.get(mode, lambda: read(sys.argv[2]))()
