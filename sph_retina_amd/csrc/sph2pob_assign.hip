@@ -516,6 +516,11 @@ __global__ __launch_bounds__(kBlock) void assign_fused_finalize_kernel(const flo
 }
 
 
+// rows per workgroup of iou_pairwise_compact_kernel: enough to amortise the per-column setup and fill the survivor stacks,
+// few enough that the grid holds thousands of workgroups; with the tail-first dispatch order, 64 GT
+// (profiles/r03y_ab_pairwise_rows.log): 98 208 anchors 18.5 us at 8 rows, 19.9 at 12, 20.2 at 16, 33.9 at 32; 392 832
+// anchors 49.1 us at 8, 47.0 at 12, 42.6 at 16, 41.1 at 22, 42.0 at 32 => about 4 096 workgroups, at least 8 rows, chunks of
+// equal size
 static int64_t pairwise_rows_per_wg(int64_t m, int64_t n) {
     const int64_t col_tiles = (n + kBlock - 1) / kBlock;
     int64_t rpw = g_pw_rows > 0 ? g_pw_rows : (m * col_tiles) / 4096;

@@ -420,12 +420,6 @@ struct AlignedLaunch {
         return launch_status();
     }
 };
-// rows per workgroup of iou_pairwise_compact_kernel: enough to amortise the per-column setup and fill the survivor stacks,
-// few enough that the grid holds thousands of workgroups; with the tail-first dispatch order, 64 GT
-// (profiles/r03y_ab_pairwise_rows.log): 98 208 anchors 18.5 us at 8 rows, 19.9 at 12, 20.2 at 16, 33.9 at 32; 392 832
-// anchors 49.1 us at 8, 47.0 at 12, 42.6 at 16, 41.1 at 22, 42.0 at 32 => about 4 096 workgroups, at least 8 rows, chunks of
-// equal size
-
 struct TransformLaunch {
     const float *b1, *b2; float *o1, *o2; int64_t n; int edge, angle, jitter; hipStream_t s; bool fast = true;
     template <int V, int D> int run() {
