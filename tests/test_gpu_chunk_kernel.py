@@ -190,3 +190,64 @@ def test_out_of_range_coordinates_are_clamped_like_the_reference_never_culled_wr
     got = S.sph2pob_standard_iou(t(bad1[rows]), t(bad2[rows]), is_aligned=True).cpu().numpy()
     d = np.abs(got - want)
     assert np.mean(d) < 1e-6 and (d > 1e-4).sum() <= 3
+
+
+def _big_boxes(n, seed):
+    """(n, 4) BFoV boxes drawn on the device (the harness's ranges): the 2^31-pair batches below never exist on the host"""
+    import torch
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    b = torch.rand((n, 4), device='cuda', generator=g)
+    b.mul_(torch.tensor([360.0, 180.0, 99.0, 99.0], device='cuda')).add_(torch.tensor([0.0, 0.0, 1.0, 1.0], device='cuda'))
+    return b
+
+
+def test_maximum_sizes_two_billion_aligned_pairs_and_a_ten_gigabyte_matrix():
+    """Maximum sizes (the reference has no limit but memory: sph_iou_api.py:48-86 works on whatever the tensors hold).
+    (i) 2^31 + 4173 aligned pairs — past every 32-bit index: the launcher leaves the chunk kernel (int indices, < 2^31 - 1024
+    pairs) for the one-lane-per-pair kernel with 64-bit indices; (ii) the largest batch the chunk kernel takes; (iii) a
+    64 x 40 000 003 pairwise matrix (2.56e9 elements: 64-bit row offsets in the compacting pairwise kernel).  Checked on
+    windows at the start, across the 2^31 boundary and at the ragged end against small calls on the same boxes, bit for bit
+    (the kernels share one arithmetic), and by the share of zero IoUs (the benchmark distribution's ~74 %)."""
+    import torch
+    import sph_retina_amd as S
+    free, _ = torch.cuda.mem_get_info()
+    if free < 100 * 2 ** 30:
+        pytest.skip('needs ~80 GB of free device memory')
+    n = 2 ** 31 + 4096 + 77
+    b1, b2 = _big_boxes(n, 5), _big_boxes(n, 6)
+    windows = [(0, 5000), (2 ** 31 - 1024 - 3000, 2 ** 31 - 1024 + 10), (2 ** 31 - 2500, 2 ** 31 + 2500), (n - 4200, n)]
+
+    def check(out, upto):
+        assert out.shape == (upto,)
+        for lo, hi in windows:
+            hi = min(hi, upto)
+            if lo >= hi:
+                continue
+            small = S.sph2pob_standard_iou(b1[lo:hi], b2[lo:hi], is_aligned=True)
+            assert torch.equal(out[lo:hi], small), (upto, lo, hi)
+        for lo in range(0, upto, 2 ** 29):                     # every part of the batch was written: zeros ~74 %, never NaN
+            part = out[lo:lo + 2 ** 22]
+            z = float((part == 0).float().mean())
+            assert 0.70 < z < 0.78 and bool(torch.isfinite(part).all()) and float(part.max()) <= 1.0, (upto, lo, z)
+
+    out = S.sph2pob_standard_iou(b1, b2, is_aligned=True)
+    check(out, n)
+    del out
+    n2 = 2 ** 31 - 1024 - 1                                     # the largest chunk-kernel batch (ragged: ends inside a chunk)
+    out = S.sph2pob_standard_iou(b1[:n2], b2[:n2], is_aligned=True)
+    check(out, n2)
+    del out, b1, b2
+    torch.cuda.empty_cache()
+    # (iii) pairwise: 64 rows x 40 000 003 columns
+    m, k = 40_000_003, 64
+    gt, anchors = _big_boxes(k, 7), _big_boxes(m, 8)
+    ov = S.sph2pob_standard_iou(gt, anchors)
+    assert ov.shape == (k, m)
+    for lo, hi in ((0, 3000), (2 ** 31 // 64 - 1500, 2 ** 31 // 64 + 1500), (m - 2051, m)):
+        small = S.sph2pob_standard_iou(gt, anchors[lo:hi])
+        assert torch.equal(ov[:, lo:hi], small), (lo, hi)
+    col = torch.randint(0, m, (4096,), device='cuda')
+    rows = torch.randint(0, k, (4096,), device='cuda')
+    assert torch.equal(ov[rows, col], S.sph2pob_standard_iou(gt[rows], anchors[col], is_aligned=True))
+    del ov, gt, anchors
+    torch.cuda.empty_cache()
