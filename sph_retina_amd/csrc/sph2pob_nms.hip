@@ -258,7 +258,9 @@ __global__ __launch_bounds__(kSweepBlock) void nms_sweep_kernel(const unsigned l
 //                        in the reference's final order (:49-52), dets = (box, score), and their count.
 // Ties are broken by the original index (stable), as in round 2.  One host read (the count) sizes the outputs.
 __device__ __forceinline__ unsigned desc_score_bits(float v) {   // larger score -> smaller unsigned
-    unsigned u = __float_as_uint(v);
+    // the order of torch's device sort (cub's radix keys): by bit pattern — +NaN first, -NaN last — except that -0 is +0
+    // (equal scores keep the index order)
+    unsigned u = __float_as_uint(v + 0.0f);
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
     return ~u;
 }

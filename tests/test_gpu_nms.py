@@ -237,6 +237,16 @@ def test_host_free_route_leaves_inputs_alone_and_handles_odd_class_ids(N):
     for ids in (small * 1_000_003, small - 3, small.to(torch.int32)):
         d2, k2 = N.sph_batched_nms(b, s, ids, cfg)
         assert torch.equal(k1, k2) and torch.equal(d1, d2)
+    # scores as torch's device sort (cub radix keys) orders them: +NaN first, -NaN last, -0 == +0 (ties keep the index order)
+    odd = s.clone()
+    odd[5], odd[77] = float('nan'), float('nan')
+    odd[77] = torch.copysign(odd[77], torch.tensor(-1.0, device='cuda'))
+    odd[[10, 12, 300]] = 0.0
+    odd[[11, 301]] = -0.0
+    d3, k3 = N.sph_batched_nms(b, odd, small, cfg)
+    g3, gk3 = _general_route(N, b, odd, small, cfg)
+    assert torch.equal(k3, gk3) and torch.equal(torch.nan_to_num(d3, nan=-7.0), torch.nan_to_num(g3, nan=-7.0))
+    assert k3[0].item() == 5 and torch.isnan(d3[0, -1]) and k3[-1].item() == 77
 
 
 def test_one_class_of_40000_boxes_is_swept_in_chunks(N, oracle):

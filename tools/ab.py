@@ -146,28 +146,28 @@ def workloads(args, torch, G):
                 return launch, ([ov] if args.workload == 'pairwise' else [ov, mo, amo, gm, gam, gi, lab])
             yield f'{args.workload} 64 x {n}', make
     elif args.workload == 'loss':
-        n = 1_000_000
-        g = torch.Generator().manual_seed(2)
-        u = torch.rand((n, 5), generator=g)
-        tgt = torch.stack([u[:, 0] * 360, u[:, 1] * 180, u[:, 2] * 99 + 1, u[:, 3] * 99 + 1, u[:, 4] * 180 - 90], 1)
-        pred = tgt + torch.randn((n, 5), generator=g) * torch.tensor([8., 8., 6., 6., 10.])
-        pred[:, 0] %= 360
-        pred[:, 1] = pred[:, 1].clamp(0.5, 179.5)
-        pred[:, 2:4] = pred[:, 2:4].clamp(1, 170)
-        pred[:, 4] = pred[:, 4].clamp(-89, 89)
-        pred, tgt = pred.cuda().contiguous(), tgt.cuda().contiguous()
-        for mode_name, mode in (('ciou', 3), ('iou', 0)):
-            def make(lib, mode=mode):
-                gp, out = torch.empty((n, 5), device='cuda'), torch.empty(1, device='cuda')
-                ws = torch.empty(lib.sph2pob_loss_sum_workspace_floats(n) + 1024, device='cuda')
-                one = torch.ones(1, device='cuda')
+      for n in ([int(v) for v in args.pairs.split(',')] if args.pairs != '1000000' else [1_000_000]):
+          g = torch.Generator().manual_seed(2)
+          u = torch.rand((n, 5), generator=g)
+          tgt = torch.stack([u[:, 0] * 360, u[:, 1] * 180, u[:, 2] * 99 + 1, u[:, 3] * 99 + 1, u[:, 4] * 180 - 90], 1)
+          pred = tgt + torch.randn((n, 5), generator=g) * torch.tensor([8., 8., 6., 6., 10.])
+          pred[:, 0] %= 360
+          pred[:, 1] = pred[:, 1].clamp(0.5, 179.5)
+          pred[:, 2:4] = pred[:, 2:4].clamp(1, 170)
+          pred[:, 4] = pred[:, 4].clamp(-89, 89)
+          pred, tgt = pred.cuda().contiguous(), tgt.cuda().contiguous()
+          for mode_name, mode in (('ciou', 3), ('iou', 0)):
+              def make(lib, mode=mode):
+                  gp, out = torch.empty((n, 5), device='cuda'), torch.empty(1, device='cuda')
+                  ws = torch.empty(lib.sph2pob_loss_sum_workspace_floats(n) + 1024, device='cuda')
+                  one = torch.ones(1, device='cuda')
 
-                def launch():
-                    rc = lib.sph2pob_loss_fwd_grad_f32(G.ptr(pred), G.ptr(tgt), None, 0, 1.0 / n, None, G.ptr(out), G.ptr(ws), G.ptr(gp), None, n, 5,
-                                                       mode, 1e-6, st)
-                    return rc | lib.sph2pob_loss_grad_scale_f32(G.ptr(gp), G.ptr(one), 0, G.ptr(gp), n, 5, st)
-                return launch, [out, gp]
-            yield f'loss {mode_name} fwd+grad 1 M RBFoV', make
+                  def launch():
+                      rc = lib.sph2pob_loss_fwd_grad_f32(G.ptr(pred), G.ptr(tgt), None, 0, 1.0 / n, None, G.ptr(out), G.ptr(ws), G.ptr(gp), None, n, 5,
+                                                         mode, 1e-6, st)
+                      return rc | lib.sph2pob_loss_grad_scale_f32(G.ptr(gp), G.ptr(one), 0, G.ptr(gp), n, 5, st)
+                  return launch, [out, gp]
+              yield f'loss {mode_name} fwd+grad {n} RBFoV', make
     elif args.workload in ('nms', 'bnms'):
         import numpy as np
         from tools.bench_configs import boxes
