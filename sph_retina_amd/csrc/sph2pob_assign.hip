@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kBlock) void assign_cols_kernel(const float* __rest
         for (int t = 0; t < kAssignRows; t++) {
             const int i = r0 + t;
             const float v = (valid && i < k) ? raw[t] : -__builtin_inff();
-            const bool up = v > best;
+            const bool up = v > best || (v != v && best == best);   // torch.max: the first NaN is the maximum and stays
             best = up ? v : best;
             besti = up ? i : besti;
             key[t] = pack_max_key(v, j) & lane_mask;   // rows past k are reduced but never written

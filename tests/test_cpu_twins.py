@@ -157,3 +157,32 @@ def test_nms_and_assigner_on_cpu(S, oracle):
     res = SphMaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0.0).assign(t(a['b_anchors']), t(a['b_gt']), gt_labels=t(a['b_labels']))
     want = a['b_c4_plain_gt_inds'] if False else a['b_c0_plain_gt_inds']   # CFGS[0] differs from these thresholds only in pos/neg
     assert res.gt_inds.shape == (3000,) and res.num_gts == 12 and int((res.gt_inds > 0).sum()) >= 12
+
+
+def test_assign_on_a_matrix_with_nan_follows_torch_max(S):
+    """torch.max treats NaN as the maximum (first NaN wins): the assignment through a NaN column / row
+    (max_iou_assigner.py:171-175 on a diverged head's boxes) must come out as the reference's torch ops give it."""
+    from sph_retina_amd.bbox.assigners import assign_wrt_overlaps
+    g = torch.Generator().manual_seed(5)
+    ov = torch.rand((7, 300), generator=g)
+    ov[:, 17] = float('nan')            # a NaN box
+    ov[2, 40] = float('nan')            # single NaNs
+    ov[5, 40] = float('nan')
+    ov[4, :] = float('nan')             # a NaN GT
+    labels = torch.arange(7)
+    res, ex = assign_wrt_overlaps(ov, labels, pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0.0, return_extras=True)
+    mo, amo = ov.max(dim=0)
+    gmo, gamo = ov.max(dim=1)
+    assert torch.equal(torch.isnan(res.max_overlaps), torch.isnan(mo))
+    assert torch.equal(torch.nan_to_num(res.max_overlaps, nan=-5.0), torch.nan_to_num(mo, nan=-5.0))
+    assert torch.equal(ex['argmax_overlaps'], amo)
+    assert torch.equal(torch.isnan(ex['gt_max_overlaps']), torch.isnan(gmo)) and torch.equal(ex['gt_argmax_overlaps'], gamo)
+    # the reference's steps on those values
+    want = torch.full((300,), -1, dtype=torch.int64)
+    want[(mo >= 0) & (mo < 0.4)] = 0
+    pos = mo >= 0.5
+    want[pos] = amo[pos] + 1
+    for i in range(7):
+        if gmo[i] >= 0.0:
+            want[ov[i] == gmo[i]] = i + 1
+    assert torch.equal(res.gt_inds, want)

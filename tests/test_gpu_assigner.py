@@ -162,6 +162,44 @@ def test_fused_equals_matrix_route_bit_for_bit(A, k, n, dim, variant):
         assert torch.equal(ov[0], ov[2])
 
 
+@pytest.mark.parametrize('which', ['box', 'gt', 'both'])
+def test_fused_equals_matrix_route_with_nan_boxes(A, which):
+    """A NaN coordinate (a diverged regression head) makes that row / column of the overlaps NaN in the reference
+    (torch.max treats NaN as the maximum: max_iou_assigner.py:171-175 then assigns through it); the fused reductions carry
+    the NaN the same way the matrix route does — bit for bit, the NaN's payload included."""
+    import sph_retina_amd as S
+    gt, boxes, labels = _scene(12, 1500, 4, 77)
+    if which in ('box', 'both'):
+        boxes[40, 2] = float('nan')
+        boxes[900, 0] = float('nan')
+    if which in ('gt', 'both'):
+        gt[5, 1] = float('nan')
+    for kw in CFGS:
+        ov, res, ex = _matrix_route(A, S, gt, boxes, labels, 'standard', None, **kw)
+        res2, ex2 = A.fused_assign(gt, boxes, labels, 'standard', return_extras=True, **kw)
+        _same(res, ex, res2, ex2)
+    assert bool(torch.isnan(ov).any())
+
+
+def test_matrix_route_with_nan_follows_torch_max(A):
+    """The (k, n) epilogue on a matrix holding NaN columns, rows and single entries against torch.max on the same device
+    tensor (what the reference computes, max_iou_assigner.py:171-175)."""
+    g = torch.Generator().manual_seed(5)
+    ov = torch.rand((70, 3000), generator=g)
+    ov[:, 17] = float('nan')
+    ov[2, 40] = float('nan')
+    ov[45, 40] = float('nan')
+    ov[33, :] = float('nan')
+    ov = ov.cuda()
+    res, ex = A.assign_wrt_overlaps(ov, torch.arange(70).cuda(), pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0.0, return_extras=True)
+    mo, amo = ov.max(dim=0)
+    gmo, gamo = ov.max(dim=1)
+    assert torch.equal(torch.isnan(res.max_overlaps), torch.isnan(mo))
+    assert torch.equal(torch.nan_to_num(res.max_overlaps, nan=-5.0), torch.nan_to_num(mo, nan=-5.0))
+    assert torch.equal(ex['argmax_overlaps'], amo)
+    assert torch.equal(torch.isnan(ex['gt_max_overlaps']), torch.isnan(gmo)) and torch.equal(ex['gt_argmax_overlaps'], gamo)
+
+
 def test_fused_assign_equals_reference_fixture(A):
     """The reference's real MaxIoUAssigner.assign on spherical boxes (tests/golden/assign.npz, part b): same assignment
     except where an anchor's IoU sits within fp32 noise of a threshold or of a row maximum tie."""
