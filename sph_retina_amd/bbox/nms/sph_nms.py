@@ -113,7 +113,7 @@ def _nms_one_class_chunked(boxes_sorted, iou_threshold, variant, chunk=16384):
         part = boxes_sorted[lo:lo + chunk]
         alive = None
         if kept is not None and kept.size(0) > 0:
-            alive = ~(iou(kept, part) > iou_threshold).any(dim=0)
+            alive = (iou(kept, part) <= iou_threshold).all(dim=0)   # `iou <= thr` keeps (a NaN IoU suppresses, as in the reference)
             part = part[alive]
         if part.size(0) == 0:
             continue

@@ -236,7 +236,7 @@ struct NmsRun {
                             if (removed[(size_t)(j - a)]) continue;
                             float y[5];
                             load_box<D>(boxes, j, y);
-                            if (pair_iou_any<V, D>(x, y, fast, MODE_IOU, edge, ANGLE_EQUATOR) > thr) removed[(size_t)(j - a)] = 1;
+                            if (!(pair_iou_any<V, D>(x, y, fast, MODE_IOU, edge, ANGLE_EQUATOR) <= thr)) removed[(size_t)(j - a)] = 1;
                         }
                     }
                 }

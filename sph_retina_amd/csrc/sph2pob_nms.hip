@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void nms_mask_kernel(const float* __restric
         if (j > i && j < seg_end) {
             float y[5];
             load_box<DIM>(boxes, j, y);
-            hit = pair_iou_sel<VARIANT, DIM, FAST>(x, y, MODE_IOU, edge, ANGLE_EQUATOR) > thr;
+            hit = !(pair_iou_sel<VARIANT, DIM, FAST>(x, y, MODE_IOU, edge, ANGLE_EQUATOR) <= thr);   // the reference keeps `iou <= thr` (sph_nms.py:72): a NaN IoU suppresses
         }
         unsigned long long bits = __builtin_amdgcn_ballot_w64(hit);
         if (lane == 0) row[r] = bits;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kBlock) void nms_mask_compact_kernel(const float* _
         auto finish_one = [&](int j) {
             float y[5];
             load_box<DIM>(boxes, j, y);
-            if (lean_finish<VARIANT, DIM, 2>(x, y, MODE_IOU, EDGE_ARC, xt) > thr) {
+            if (!(lean_finish<VARIANT, DIM, 2>(x, y, MODE_IOU, EDGE_ARC, xt) <= thr)) {   // `iou <= thr` keeps: NaN suppresses
                 const int rel = j - (int)(base << 6);
                 atomicOr(&bm[rel >> 5], 1u << (rel & 31));
             }

@@ -186,3 +186,14 @@ def test_assign_on_a_matrix_with_nan_follows_torch_max(S):
         if gmo[i] >= 0.0:
             want[ov[i] == gmo[i]] = i + 1
     assert torch.equal(res.gt_inds, want)
+
+
+def test_nms_with_nan_boxes_on_cpu_follows_the_reference_loop(S):
+    """`iou <= thr` keeps (sph_nms.py:72): a NaN IoU suppresses.  The host twin against the reference's loop run on this
+    package's own CPU IoUs."""
+    from sph_retina_amd.bbox.nms import sph_batched_nms
+    from test_gpu_nms import _loop_with, _nan_scene
+    b, s, idxs, top0, mid1 = _nan_scene()
+    want = _loop_with(S.sph2pob_efficient_iou, t(b), t(s), t(idxs), 0.5)
+    dets, keep = sph_batched_nms(t(b), t(s), t(idxs), dict(iou_threshold=0.5), 'efficient')
+    assert keep.tolist() == want and top0 in want and mid1 not in want

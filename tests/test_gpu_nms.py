@@ -278,3 +278,50 @@ def test_one_class_of_40000_boxes_is_swept_in_chunks(N, oracle):
     _, kr = N.SphNMS()(cu(b2[rest]), cu(s2[rest]), cu(idxs[rest]), dict(iou_threshold=0.5))
     assert set(rest[kr.cpu().numpy()].tolist()) == set(k2[k2 >= k].tolist())
     assert (np.diff(s2[k2]) <= 0).all()
+
+
+def _nan_scene():
+    rng = np.random.default_rng(12)
+    k = 240
+    b = np.stack([100 + rng.random(k) * 40, 70 + rng.random(k) * 30, 5 + rng.random(k) * 30, 5 + rng.random(k) * 30], 1).astype(np.float32)
+    s = rng.random(k).astype(np.float32)
+    idxs = rng.integers(0, 3, k)
+    top0 = np.flatnonzero(idxs == 0)[np.argmax(s[idxs == 0])]        # the best box of class 0 is NaN: it is kept and, its IoU
+    b[top0, 2] = np.nan                                              # with everything being NaN, nothing else of the class is
+    mid1 = np.flatnonzero(idxs == 1)[np.argsort(-s[idxs == 1])[7]]   # a NaN box further down class 1: removed by the first kept box
+    b[mid1, 0] = np.nan
+    return b, s, idxs, top0, mid1
+
+
+def _loop_with(iou_fn, boxes, scores, idxs, thr):
+    """The reference's loops (sph_nms.py:39-52 per class, :62-74 greedy) on the IoUs `iou_fn` gives: whether a NaN box yields a
+    NaN IoU is the IoU operator's business (mmcv's planar kernel is absent: unpinned); what NMS does with one is the
+    loop's — `iou <= thr` keeps."""
+    keep_all = []
+    for c in torch.unique(idxs).tolist():
+        ids = torch.nonzero(idxs == c).flatten()
+        order = ids[torch.argsort(scores[ids], descending=True, stable=True)]
+        while order.numel() > 0:
+            keep_all.append(int(order[0]))
+            if order.numel() == 1:
+                break
+            iou = iou_fn(boxes[order[:1]], boxes[order[1:]]).reshape(-1)
+            order = order[1:][iou <= thr]
+    keep = torch.tensor(sorted(keep_all), device=scores.device)
+    return keep[torch.argsort(scores[keep], descending=True, stable=True)].tolist()
+
+
+def test_nan_boxes_suppress_like_the_reference_loop(N):
+    """sph_nms.py:69-73 keeps `iou <= thr`: a NaN IoU fails the test, so a NaN box suppresses (when kept) or is suppressed
+    (otherwise).  Fused route, torch-sorted route and the single-class operator against the loop run on this package's IoUs."""
+    import sph_retina_amd as S
+    b, s, idxs, top0, mid1 = _nan_scene()
+    tb, ts, ti = cu(b), cu(s), cu(idxs)
+    want = _loop_with(S.sph2pob_efficient_iou, tb, ts, ti, 0.5)
+    assert top0 in want and mid1 not in want and int((idxs[want] == 0).sum()) == 1
+    dets, keep = N.sph_batched_nms(tb, ts, ti, dict(iou_threshold=0.5), 'efficient')
+    gdets, gkeep = _general_route(N, tb, ts, ti, dict(iou_threshold=0.5))
+    assert keep.tolist() == want and gkeep.tolist() == want
+    one = torch.from_numpy(idxs == 1)
+    w1 = _loop_with(S.sph2pob_efficient_iou, tb[one], ts[one], torch.zeros(int(one.sum()), dtype=torch.long, device=tb.device), 0.5)
+    assert N.sph_nms_op(tb[one], ts[one], 0.5).tolist() == w1
