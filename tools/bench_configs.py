@@ -113,8 +113,18 @@ def config3(n=1_000_000):
         lib.sph2pob_loss_fwd_grad_f32(G.ptr(p_), G.ptr(t_), null, 0, ctypes.c_float(1.0 / n), null, ctypes.c_void_p(out.data_ptr()),
                                       G.ptr(ws2), G.ptr(stash), null, nn, 5, 3, ctypes.c_float(1e-6), st)
         lib.sph2pob_loss_grad_scale_f32(G.ptr(stash), ctypes.c_void_p(half.data_ptr()), 0, G.ptr(gp), nn, 5, st)
+    def abi_step_root():   # the loss is the root of the graph (upstream gradient 1 known on the host: a C / C++ training loop):
+        # forward + gradients + final sum, no scale launch; and the same without the scalar loss (gradients only)
+        lib.sph2pob_loss_fwd_grad_f32(G.ptr(p_), G.ptr(t_), null, 0, ctypes.c_float(1.0 / n), null, ctypes.c_void_p(out.data_ptr()),
+                                      G.ptr(ws2), G.ptr(stash), null, nn, 5, 3, ctypes.c_float(1e-6), st)
+
+    def abi_step_grad_only():
+        lib.sph2pob_loss_fwd_grad_f32(G.ptr(p_), G.ptr(t_), null, 0, ctypes.c_float(1.0 / n), null, null, null, G.ptr(stash), null, nn, 5, 3,
+                                      ctypes.c_float(1e-6), st)
     tb = timeit(abi_step_two_pass)
     ta = timeit(abi_step)
+    tr = timeit(abi_step_root)
+    tgo = timeit(abi_step_grad_only)
     ts = timeit(abi_step_scaled)
     # the same Python step with the host out of the way: captured once (torch's whole-network recipe: forward, backward
     # and the accumulation into pred.grad in one hipGraph), replayed
@@ -135,7 +145,7 @@ def config3(n=1_000_000):
     except Exception as e:   # noqa: BLE001  (reported, not fatal: the table's other figures do not depend on it)
         print('graph capture of the loss step failed:', e, file=sys.stderr)
     return {'config': 'configs[2]: 1,000,000 RBFoV pairs, Sph2Pob + CIoU loss forward+backward', 'pairs': n,
-            'autograd_fwd_bwd_ms': t * 1e3, 'autograd_fwd_ms': tf * 1e3, 'c_abi_fwd_bwd_ms': ta * 1e3,
+            'autograd_fwd_bwd_ms': t * 1e3, 'autograd_fwd_ms': tf * 1e3, 'c_abi_fwd_bwd_ms': ta * 1e3, 'c_abi_root_loss_ms': tr * 1e3, 'c_abi_gradients_only_ms': tgo * 1e3,
             'c_abi_two_pass_fwd_bwd_ms': tb * 1e3, 'c_abi_fwd_bwd_scaled_grad_ms': ts * 1e3, 'graph_replay_fwd_bwd_ms': tg * 1e3 if tg else None,
             'pairs_per_s_c_abi': n / ta, 'pairs_per_s_autograd': n / t, 'pairs_per_s_graph_replay': n / tg if tg else None,
             'algorithmic_bytes_per_pair': 108, 'hbm_GBps_c_abi': 108 * n / ta / 1e9,
