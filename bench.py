@@ -16,7 +16,8 @@ One "step" = one pass of the hot path over one batch of synthetic boxes resident
           and the step INCLUDES the north-star exchange: one RCCL `all_gather_into_tensor` of the per-shard IoU vectors
           per step, double-buffered so that the collective of step i (RCCL's stream) overlaps the kernel of step i+1.
           Box pairs are independent, so computing needs no collective; the consumers (assigner, loss, NMS) shard the
-          same way.  The same job therefore also times the step WITHOUT the gather (`no_gather`) and, on rank 0, the
+          same way.  The same job therefore also times the step WITHOUT the gather (`no_gather`), the gather ALONE
+          (`gather_only`: what bounds the step once the collective outlasts the kernel) and, on rank 0, the
           whole batch on one GPU (`strong_scaling.one_gpu_ms`), so that the line carries the speed-ups by itself.
   `--scaling weak --pairs P` keeps P pairs per GPU instead; `--total-pairs T` changes the batch.
 `value` = pairs processed by all ranks / max-over-ranks wall time of the K timed steps.
@@ -355,10 +356,23 @@ def main(argv=None):
     for i in range(max(settle - args.warmup - (args.steps if extras else 0), 0)):
         step(i, gather)
     elapsed = timed(args.steps, gather)
-    no_gather = None
+    no_gather = gather_only = None
     if gather:
         el = timed(args.steps, False)
         no_gather = {'ms_per_step': el / args.steps * 1e3, 'value': total * args.steps / el}
+        # ... and the exchange alone (no kernel): what bounds the step when the collective outlasts the 7 us kernel
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            dist.all_gather_into_tensor(gathered[i & 1], shards[i & 1])
+        barrier()
+        el = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        gather_only = {'ms_per_step': el / args.steps * 1e3, 'bytes_received_per_rank': (world - 1) * n * 4,
+                       'note': 'all_gather_into_tensor of the shards alone; the step cannot be shorter than this'}
     checksum = float(shards[0].double().sum().item())
     iou_benched = shards[0].clone() if (world == 1 and not dry and not args.no_parity) else None
 
@@ -495,6 +509,8 @@ def main(argv=None):
             out['two_streams'] = two_streams
         if no_gather:
             out['no_gather'] = no_gather
+        if gather_only:
+            out['gather_only'] = gather_only
         if world > 1 and scaling == 'strong':
             ss = {'total_pairs': total, 'one_gpu_ms': one_gpu_ms}
             if one_gpu_ms:
