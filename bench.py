@@ -11,15 +11,15 @@ launched by torch.distributed.run directly (WORLD_SIZE set) it is one of the ran
 One "step" = one pass of the hot path over one batch of synthetic boxes resident in HBM: aligned
 `sph2pob_standard_iou` (closed-form arithmetic, the default) over the batch.
   N = 1   1,000,000 BFoV pairs (BASELINE.json configs[1]).
-  N > 1   strong scaling of configs[4]: 8,000,000 BFoV pairs in total, rank r owns the contiguous slice
-          [r T/N, (r+1) T/N) (generated on the rank: scattering 36 B/pair over xGMI would cost more than computing),
-          and the step INCLUDES the north-star exchange: one RCCL `all_gather_into_tensor` of the per-shard IoU vectors
-          per step, double-buffered so that the collective of step i (RCCL's stream) overlaps the kernel of step i+1.
-          Box pairs are independent, so computing needs no collective; the consumers (assigner, loss, NMS) shard the
-          same way.  The same job therefore also times the step WITHOUT the gather (`no_gather`), the gather ALONE
-          (`gather_only`: what bounds the step once the collective outlasts the kernel) and, on rank 0, the
-          whole batch on one GPU (`strong_scaling.one_gpu_ms`), so that the line carries the speed-ups by itself.
-  `--scaling weak --pairs P` keeps P pairs per GPU instead; `--total-pairs T` changes the batch.
+  N > 1   the same batch on EVERY GPU (1,000,000 pairs per rank, generated on the rank), no data-path collective: box pairs are
+          independent and the consumers (assigner, loss, NMS) shard the same way, so computing needs no exchange
+          ("scaling": "weak").  The north star's exchange — configs[4]: 8,000,000 pairs split N ways and ONE RCCL
+          `all_gather_into_tensor` of the per-shard IoU vectors per step, double-buffered so that the collective of step i
+          overlaps the kernel of step i+1 — is measured in the same job and reported beside it (`north_star_configs4`: with
+          the gather, without it, the gather alone, and the speed-ups against the whole batch on one GPU): the 7 us kernel is
+          shorter than any collective of 32 MB, so that figure is the collective's, not the kernel's.
+          `--scaling strong [--no-gather]` makes configs[4] the timed step instead.
+  `--pairs P` changes the pairs per GPU; `--total-pairs T` (strong) the batch.
 `value` = pairs processed by all ranks / max-over-ranks wall time of the K timed steps.
 Timing: W warm-up steps as asked, topped up to 3 000 untimed steps (the clocks only settle after a few thousand
 back-to-back launches; reported as config.untimed_steps_before_timing, and the figure measured with exactly W warm-up
@@ -77,8 +77,9 @@ def parse_args(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5000)
     ap.add_argument('--warmup', type=int, default=500)
-    ap.add_argument('--scaling', default='strong', choices=['strong', 'weak'],
-                    help='N > 1: strong = --total-pairs split N ways (default); weak = --pairs per GPU')
+    ap.add_argument('--scaling', default=None, choices=['strong', 'weak'],
+                    help='N > 1: weak = --pairs per GPU, no collective (default); strong = --total-pairs split N ways with the '
+                         'all-gather in the step (the north-star configuration, otherwise measured beside the default)')
     ap.add_argument('--total-pairs', type=int, default=None, help='strong scaling: pairs per step over all ranks '
                     f'(default {PAIRS_ONE_GPU:,} for one GPU, {PAIRS_SHARDED:,} for several)')
     ap.add_argument('--pairs', type=int, default=None, help='pairs per GPU per step (weak scaling; one GPU: the batch)')
@@ -89,10 +90,12 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true', help='skip the max |dIoU| block (oracle on the host, outside the timed region)')
     ap.add_argument('--gather', dest='gather', action='store_true', default=None,
-                    help='N > 1: one RCCL all-gather of the per-shard IoU vectors per step, pipelined one step deep (default)')
+                    help='N > 1: one RCCL all-gather of the per-shard IoU vectors per step, pipelined one step deep '
+                         '(default with --scaling strong)')
     ap.add_argument('--no-gather', dest='gather', action='store_false', help='N > 1: time the sharded step only')
     ap.add_argument('--no-extras', action='store_true', help='skip the cold-HBM / 8 M-pair / unsettled side measurements')
     ap.add_argument('--force-dist', action='store_true', help='initialise the process group even with one rank (tests)')
+    ap.add_argument('--north-star', action='store_true', help='with --force-dist: run the configs[4] exchange phase with one rank too (tests)')
     ap.add_argument('--dry-run', action='store_true',
                     help='CPU rehearsal of the launch / shard / gather logic on gloo with a stand-in operator (no kernel, '
                          'no roofline): what the CPU test-suite drives')
@@ -100,14 +103,72 @@ def parse_args(argv=None):
 
 
 def shard_plan(args, world):
-    """(pairs per rank as a list, total, label)."""
+    """(pairs per rank as a list, total, label).  Default: the same batch on every GPU (configs[1] per rank: 'weak'); with
+    --scaling strong (or --total-pairs) one batch split N ways."""
     from sph_retina_amd.parallel import shard_bounds
-    if world > 1 and args.scaling == 'weak':
+    scaling = args.scaling or ('strong' if args.total_pairs else 'weak')
+    if scaling == 'weak':
         per = args.pairs or PAIRS_ONE_GPU
         return [per] * world, per * world, 'weak'
     total = args.total_pairs or (args.pairs if world == 1 and args.pairs else (PAIRS_ONE_GPU if world == 1 else PAIRS_SHARDED))
     counts = [hi - lo for lo, hi in (shard_bounds(total, world, r) for r in range(world))]
     return counts, total, 'strong'
+
+
+def north_star_exchange(kernel, make, world, rank, dev, dist, steps, warmup, barrier_fn, dry):
+    """configs[4] as the north star writes it, measured beside the default: 8 M pairs split over the ranks, ONE
+    `all_gather_into_tensor` of the per-shard IoU vectors per step, double-buffered so that the collective of step i overlaps
+    the kernel of step i + 1 — then the same without the gather, and the gather alone.  Every rank runs this."""
+    import torch
+    from sph_retina_amd.parallel import shard_bounds
+    total = PAIRS_SHARDED
+    lo, hi = shard_bounds(total, world, rank)
+    n = hi - lo
+    if any((b - a) != n for a, b in (shard_bounds(total, world, r) for r in range(world))):
+        return None   # the collective needs equal shards
+    b1, b2 = make(n, 300 + 2 * rank, dev), make(n, 301 + 2 * rank, dev)
+    shards = [torch.empty(n, dtype=torch.float32, device=dev) for _ in range(2)]
+    gathered = [torch.empty(world * n, dtype=torch.float32, device=dev) for _ in range(2)]
+    pending = [None, None]
+
+    def step(i, with_gather):
+        k = i & 1
+        if with_gather and pending[k] is not None:
+            pending[k].wait()
+        kernel(b1, b2, shards[k], n)
+        if with_gather:
+            pending[k] = dist.all_gather_into_tensor(gathered[k], shards[k], async_op=True)
+
+    def drain():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
+
+    def timed(fn):
+        drain()
+        barrier_fn()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(i)
+        drain()
+        barrier_fn()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    for i in range(warmup):
+        step(i, True)
+    el_g = timed(lambda i: step(i, True))
+    el_n = timed(lambda i: step(i, False))
+    el_o = timed(lambda i: dist.all_gather_into_tensor(gathered[i & 1], shards[i & 1]))
+    ok = bool(torch.equal(gathered[0][lo:hi], shards[0]))
+    return {'config': f'BASELINE configs[4]: {total:,} pairs split over {world} GPUs, one RCCL all-gather of the shards per step '
+                      '(pipelined one step deep)', 'total_pairs': total, 'pairs_per_gpu': n, 'steps': steps,
+            'with_gather': {'ms_per_step': el_g / steps * 1e3, 'value': total * steps / el_g},
+            'no_gather': {'ms_per_step': el_n / steps * 1e3, 'value': total * steps / el_n},
+            'gather_only': {'ms_per_step': el_o / steps * 1e3, 'bytes_received_per_rank': (world - 1) * n * 4},
+            'own_shard_intact_in_gathered': ok}
 
 
 def self_launch(args, argv):
@@ -268,7 +329,7 @@ def main(argv=None):
     counts, total, scaling = shard_plan(args, world)
     n = counts[rank]
     equal = len(set(counts)) == 1
-    gather = (world > 1) if args.gather is None else (args.gather and use_dist)
+    gather = (world > 1 and scaling == 'strong') if args.gather is None else (args.gather and use_dist)
     if gather and not equal:
         raise SystemExit('--gather needs equal shards (total pairs divisible by the number of GPUs)')
 
@@ -374,6 +435,11 @@ def main(argv=None):
         gather_only = {'ms_per_step': el / args.steps * 1e3, 'bytes_received_per_rank': (world - 1) * n * 4,
                        'note': 'all_gather_into_tensor of the shards alone; the step cannot be shorter than this'}
     checksum = float(shards[0].double().sum().item())
+    # the north star's exchange (configs[4]: 8 M pairs split N ways + one all-gather per step), measured beside the default
+    north_star = None
+    if ((world > 1 and not args.no_extras) or (args.north_star and use_dist)) and scaling == 'weak' and not gather:
+        north_star = north_star_exchange(kernel, make_boxes, world, rank, dev, dist, min(args.steps, 500),
+                                         min(max(args.warmup, 20), 200), barrier, dry)
     iou_benched = shards[0].clone() if (world == 1 and not dry and not args.no_parity) else None
 
     # ---- side measurements on rank 0 (the other ranks wait at the final barrier) ----
@@ -474,6 +540,8 @@ def main(argv=None):
             'data': 'synthetic' if not dry else 'dry-run (gloo, stand-in operator, no kernel)',
             'config': {'workload': (f'{total:,} uniform random BFoV pairs per step, sph2pob_{args.variant}_iou aligned: '
                                     + ('BASELINE configs[1] on one GPU' if world == 1 and total == PAIRS_ONE_GPU else
+                                       'BASELINE configs[1] on every GPU, no collective (pairs are independent; the consumers shard '
+                                       'the same way)' if scaling == 'weak' and counts[0] == PAIRS_ONE_GPU else
                                        'BASELINE configs[4]' if total == PAIRS_SHARDED else 'custom batch')
                                     + (f', contiguous shards of {counts[0]:,} pairs on {world} GPUs' if world > 1 else '')
                                     + (', one RCCL all-gather of the shards per step, pipelined one step deep' if gather else '')),
@@ -511,6 +579,12 @@ def main(argv=None):
             out['no_gather'] = no_gather
         if gather_only:
             out['gather_only'] = gather_only
+        if north_star:
+            if at_8m:   # rank 0's one-GPU time of the whole 8 M batch: the speed-ups of the strong-scaling curve
+                north_star['one_gpu_ms'] = at_8m['kernel_ms']
+                north_star['speedup_with_gather'] = at_8m['kernel_ms'] / north_star['with_gather']['ms_per_step']
+                north_star['speedup_no_gather'] = at_8m['kernel_ms'] / north_star['no_gather']['ms_per_step']
+            out['north_star_configs4'] = north_star
         if world > 1 and scaling == 'strong':
             ss = {'total_pairs': total, 'one_gpu_ms': one_gpu_ms}
             if one_gpu_ms:

@@ -33,7 +33,7 @@ def check(d, steps, warmup):
     for k in KEYS:
         assert k in d, k
     assert d['unit'] == 'pairs/s' and d['n_gpus'] == 1 and d['steps'] == steps and d['warmup'] == warmup
-    assert d['higher_is_better'] is True and d['scaling'] == 'strong' and d['vs_baseline'] is None and d['dtype'] == 'f32'
+    assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None and d['dtype'] == 'f32'
     assert 'workload' in d['config'] and 'model' not in d['config']
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
@@ -82,8 +82,13 @@ def test_bench_single_process_contract():
 def test_bench_under_torch_distributed_run_one_rank():
     d = run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
              '--master-port', '29577', 'bench.py', '--gpus', '1', '--steps', '100', '--warmup', '10', '--force-dist',
-             '--no-cpu-baseline', '--no-extras'])
+             '--no-cpu-baseline', '--no-extras', '--north-star'])
     check(d, 100, 10)
+    # the north star's exchange phase (configs[4] + all_gather_into_tensor) on real RCCL, one rank: the code the N > 1 runs take
+    ns = d['north_star_configs4']
+    assert ns['total_pairs'] == 8_000_000 and ns['pairs_per_gpu'] == 8_000_000 and ns['own_shard_intact_in_gathered'] is True
+    assert 0.03 < ns['no_gather']['ms_per_step'] < 0.2 and ns['with_gather']['ms_per_step'] >= 0.9 * ns['no_gather']['ms_per_step']
+    assert ns['gather_only']['ms_per_step'] > 0
 
 
 @pytest.mark.parametrize('scenario', ['recipe', 'stale'])
