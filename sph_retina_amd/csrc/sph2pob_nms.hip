@@ -164,6 +164,9 @@ __global__ __launch_bounds__(kBlock) void nms_mask_compact_kernel(const float* _
 // stage two blocks deep — wave 0 carrying words b + 1 and b + 2 in registers, the workers' loads left in flight across an
 // LDS-only barrier — was built and measured: 91 us against this form's 83 for one class of 5 000, 15.4 against 12.8 us
 // for 37 classes; the compiler waits for the loads at the loop's register copies anyway.  Not kept.)
+// (Blocks of 128 or 256 rows — two / four diagonal words per row, half / a quarter of the barriers — were built and measured in
+// round 3, bit-equal: 145 / 162 us against 147 for one class of 5 000, 39.7 / 45.0 against 38.2 us for 37 classes
+// (profiles/r06t_sweep_rb.log): the sweep's time is the kept rows' work, not the number of pipeline periods.  Not kept.)
 constexpr int kSweepBlock = 512, kSweepCands = 4;
 __global__ __launch_bounds__(kSweepBlock) void nms_sweep_kernel(const unsigned long long* __restrict__ mask,
                                                                 const int64_t* __restrict__ cls, int64_t k, int words,
