@@ -115,12 +115,23 @@ __global__ __launch_bounds__(kBlock) void nms_mask_compact_kernel(const float* _
         load_box<DIM>(boxes, i, x);
         const CullBox cx = cull_box(x, EDGE_ARC);
         const ColatTrig xt = colat_trig(x[1], 1);   // the row's colatitude trig: once per row, not once per surviving pair
+        // VARIANT_UNBIASED (the spherical rectangles' exact intersection area, fp64): the rectangles lie inside the caps the cull
+        // compares — a rectangle's corners are at atan(sqrt(tan^2(a/2) + tan^2(b/2))) <= sqrt(a^2 + b^2) / 2 from its centre —
+        // so a culled pair has intersection 0.  For RBFoV that is IoU 0; the BFoV form returns (0 + 1e-8) / (A1 + A2 - 1e-8)
+        // (unbiased_iou_bfov.py:200), which stays at or below thr as long as A1 + A2 >= 1e-8 (1 + 1 / thr): tested on a lower
+        // bound of the areas (A >= 4 a b / pi^2), twice over; degenerate boxes and thr <= 0 are never culled.
+        const float xab = fminf(fmaxf(x[2], 0.0f), 180.0f) * fminf(fmaxf(x[3], 0.0f), 180.0f);   // (out-of-range / NaN extents count as 0)
+        const float ub_need = thr > 0.0f ? 2e-8f * (1.0f + 1.0f / thr) / 1.2345679e-4f : __builtin_inff();   // in deg^2: 4 / 180^2
+        (void)xab; (void)ub_need;
         int* st = stack[wave];
         int count = 0;
         auto finish_one = [&](int j) {
             float y[5];
             load_box<DIM>(boxes, j, y);
-            if (!(lean_finish<VARIANT, DIM, 2>(x, y, MODE_IOU, EDGE_ARC, xt) <= thr)) {   // `iou <= thr` keeps: NaN suppresses
+            float v;
+            if constexpr (VARIANT == VARIANT_UNBIASED) v = unbiased_pair_iou<DIM, false>(x, y);
+            else v = lean_finish<VARIANT, DIM, 2>(x, y, MODE_IOU, EDGE_ARC, xt);
+            if (!(v <= thr)) {   // `iou <= thr` keeps: NaN suppresses
                 const int rel = j - (int)(base << 6);
                 atomicOr(&bm[rel >> 5], 1u << (rel & 31));
             }
@@ -133,6 +144,8 @@ __global__ __launch_bounds__(kBlock) void nms_mask_compact_kernel(const float* _
                 float y[5];
                 load_box<DIM>(boxes, j, y);
                 surv = !cull_pair(cx, cull_box(y, EDGE_ARC));
+                if constexpr (VARIANT == VARIANT_UNBIASED && DIM == 4)
+                    surv |= !(fmaf(fminf(fmaxf(y[2], 0.0f), 180.0f), fminf(fmaxf(y[3], 0.0f), 180.0f), xab) >= ub_need);
             }
             const unsigned long long m = __builtin_amdgcn_ballot_w64(surv);
             if (surv) st[count + rank_below(m)] = (int)j;
@@ -465,9 +478,10 @@ static int nms_mask_and_sweep(const float* boxes_sorted, const int64_t* cls_sort
 #define SPH_NMS_COMPACT(V, D) \
     hipLaunchKernelGGL((nms_mask_compact_kernel<V, D>), grid, dim3(kBlock), 0, s, boxes_sorted, cls_sorted, k, words, iou_threshold, mask)
     const bool compact = fast && !g_no_compact && k < ((int64_t)1 << 31) - 64 &&
-                         (variant == SPH2POB_VARIANT_EFFICIENT || variant == SPH2POB_VARIANT_STANDARD);
+                         (variant == SPH2POB_VARIANT_EFFICIENT || variant == SPH2POB_VARIANT_STANDARD || variant == SPH2POB_VARIANT_UNBIASED);
     if (compact) {
-        if (variant == SPH2POB_VARIANT_EFFICIENT) { if (box_dim == 4) SPH_NMS_COMPACT(1, 4); else SPH_NMS_COMPACT(1, 5); }
+        if (variant == SPH2POB_VARIANT_UNBIASED) { if (box_dim == 4) SPH_NMS_COMPACT(5, 4); else SPH_NMS_COMPACT(5, 5); }
+        else if (variant == SPH2POB_VARIANT_EFFICIENT) { if (box_dim == 4) SPH_NMS_COMPACT(1, 4); else SPH_NMS_COMPACT(1, 5); }
         else { if (box_dim == 4) SPH_NMS_COMPACT(0, 4); else SPH_NMS_COMPACT(0, 5); }
     } else if (variant == SPH2POB_VARIANT_EFFICIENT) {
         if (box_dim == 4) { if (fast) SPH_NMS_LAUNCH(1, 4, true); else SPH_NMS_LAUNCH(1, 4, false); }

@@ -309,3 +309,34 @@ def test_gpu_naive_both_formators_and_planar_nms(oracle, formator):
             alive &= ~(iou[i] > 0.5)
             alive[i] = False
     assert keep.tolist() == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dim', [4, 5])
+@pytest.mark.parametrize('thr', [0.5, 0.05, 0.0])
+def test_gpu_unbiased_nms_compaction_never_changes_a_decision(dim, thr):
+    """Round 3: the Unbiased-IoU NMS culls a row's far columns with the bounding caps and runs the exact fp64 path on the
+    survivors only (nms_mask_compact_kernel<VARIANT_UNBIASED>).  The keep list must be that of the reference's loop
+    (sph_nms.py:62-74) run on this package's own pairwise unbiased IoU — the one-lane kernel, no cull — including where the
+    BFoV form's far value 1e-8 / (A1 + A2) matters: near-degenerate boxes (it exceeds thr there and the reference's loop
+    suppresses DISJOINT boxes) and thr = 0 (nothing may be culled)."""
+    import sph_retina_amd as S
+    from test_gpu_nms import _loop_with
+    rng = np.random.default_rng(100 + dim)
+    k = 1500
+    centres = np.stack([rng.random(60) * 360, 20 + rng.random(60) * 140, 5 + rng.random(60) * 50, 5 + rng.random(60) * 50,
+                        -60 + rng.random(60) * 120], 1).astype(np.float32)[:, :dim]
+    b = centres[rng.integers(0, 60, k)] + rng.normal(0, 2.0, (k, dim)).astype(np.float32)
+    b[:, 0] %= 360
+    b[:, 1] = np.clip(b[:, 1], 1, 179)
+    b[:, 2:4] = np.clip(b[:, 2:4], 2, 120)
+    b[::50, 2:4] = rng.random((len(b[::50]), 2)).astype(np.float32) * 2e-3      # near-degenerate boxes (down to the jitter's floor)
+    b[7::90, 2:4] = 0.0
+    s = rng.random(k).astype(np.float32)
+    idxs = rng.integers(0, 4, k)
+    tb, ts, ti = cu(b), cu(s), cu(idxs)
+    calc = S.SphOverlaps2D(backend='unbiased_iou', box_version=dim)
+    want = _loop_with(lambda x, y: calc(x, y), tb, ts, ti, thr)
+    dets, keep = S.SphNMS('unbiased_iou')(tb, ts, ti, dict(iou_threshold=thr))
+    assert keep.tolist() == want
+    assert len(want) < k   # something was suppressed
