@@ -330,7 +330,9 @@ def test_gpu_unbiased_nms_compaction_never_changes_a_decision(dim, thr):
     b[:, 0] %= 360
     b[:, 1] = np.clip(b[:, 1], 1, 179)
     b[:, 2:4] = np.clip(b[:, 2:4], 2, 120)
-    b[::50, 2:4] = rng.random((len(b[::50]), 2)).astype(np.float32) * 2e-3      # near-degenerate boxes (down to the jitter's floor)
+    b[::25, 2:4] = (0.004 + rng.random((len(b[::25]), 1)) * 0.016).astype(np.float32)   # near-degenerate squares of 0.004 ... 0.02 deg: the band in
+    # which the BFoV far value 1e-8 / (A1 + A2 - 1e-8) of two DISJOINT boxes is 1.0 ... 0.04 (measured: 0.005 deg -> 1.0, 0.008 -> 0.35,
+    # 0.012 -> 0.13, 0.02 -> 0.043): the reference's loop suppresses them, so the cull must not take them
     b[7::90, 2:4] = 0.0
     s = rng.random(k).astype(np.float32)
     idxs = rng.integers(0, 4, k)
@@ -340,3 +342,6 @@ def test_gpu_unbiased_nms_compaction_never_changes_a_decision(dim, thr):
     dets, keep = S.SphNMS('unbiased_iou')(tb, ts, ti, dict(iou_threshold=thr))
     assert keep.tolist() == want
     assert len(want) < k   # something was suppressed
+    if dim == 4 and thr > 0:   # ... including near-degenerate boxes that touch nothing (the far value alone removed them)
+        tiny = set(range(0, k, 25)) - set(range(7, k, 90))
+        assert len(tiny - set(want)) > 0
