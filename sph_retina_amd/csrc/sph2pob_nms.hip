@@ -179,7 +179,11 @@ __global__ __launch_bounds__(kBlock) void nms_mask_compact_kernel(const float* _
 // for 37 classes; the compiler waits for the loads at the loop's register copies anyway.  Not kept.)
 // (Blocks of 128 or 256 rows — two / four diagonal words per row, half / a quarter of the barriers — were built and measured in
 // round 3, bit-equal: 145 / 162 us against 147 for one class of 5 000, 39.7 / 45.0 against 38.2 us for 37 classes
-// (profiles/r06t_sweep_rb.log): the sweep's time is the kept rows' work, not the number of pipeline periods.  Not kept.)
+// (profiles/r06t_sweep_rb.log).  Not kept.  Nor were, later in the round: the same with a 1 024-thread workgroup so that the OR stage's
+// tasks fit one round (144 us, r07f_sweep.log), and dense copies of each row's diagonal word and the word after it so that the
+// serial chain's prefetch is 8 cache lines per block instead of 128 (148 us, r07g_diag.log).  What IS known: one class of 1 000 /
+// 2 500 / 5 000 / 10 000 / 20 000 boxes sweeps in 16.5 / 40.3 / 79.2 / 184 / 523 us — ~1 us per 64 rows up to 5 000 boxes
+// whatever the block size, the workgroup's size or the layout of the words the chain reads; VALU issue 0.6 % (r07b PMC).)
 constexpr int kSweepBlock = 512, kSweepCands = 4;
 __global__ __launch_bounds__(kSweepBlock) void nms_sweep_kernel(const unsigned long long* __restrict__ mask,
                                                                 const int64_t* __restrict__ cls, int64_t k, int words,
