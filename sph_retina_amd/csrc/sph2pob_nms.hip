@@ -212,56 +212,71 @@ __global__ __launch_bounds__(kSweepBlock) void nms_sweep_kernel(const unsigned l
             const int64_t row = (base + b) * 64 + lane;
             return (wave == 0 && b <= b_last && w <= b_last && row >= s && row < seg_end) ? mask[row * words + w] : 0ull;
         };
-        unsigned long long diag_next = load_word(0, 0), after_next = load_word(0, 1);
+        // Three register sets in rotation (the block loop is unrolled by three so that the sets are named statically): block b's
+        // words are requested right AFTER block b - 2 is resolved and used two barriers later.  (Round 2 requested block b + 1's
+        // words at the top of iteration b: the s_waitcnt vmcnt(0) in front of block b's first v_readlane then waited for them as
+        // well — loads retire in order — and every block paid a full trip to the mask, ~1 us, whatever else was done to it.
+        // The barrier is the LDS-only one for the same reason: __syncthreads() waits for every outstanding load and store.)
+        unsigned long long dg[3], af[3];
+        dg[0] = load_word(0, 0); af[0] = load_word(0, 1);
+        dg[1] = load_word(1, 1); af[1] = load_word(1, 2);
+        dg[2] = 0ull; af[2] = 0ull;
         unsigned long long carry = 0ull;   // wave 0, uniform: what block b - 1's kept rows remove in word b
-        for (int b = 0; b <= b_last; b++) {
-            if (wave == 0) {
-                const int64_t row = (base + b) * 64 + lane;
-                const bool mine = row >= s && row < seg_end;
-                const unsigned long long diag = diag_next, after = after_next;
-                diag_next = load_word(b + 1, b + 1);
-                after_next = load_word(b + 1, b + 2);
-                const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-                const unsigned alo = (unsigned)after, ahi = (unsigned)(after >> 32);
-                // scalar (SGPR) state of the serial chain; rows of the block outside this segment start out "removed"
-                // (the readlane builtins return int: cast before widening, or bit 31 sign-extends)
-                unsigned long long rem = removed[b] | carry | ~__builtin_amdgcn_ballot_w64(mine);
-                rem = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(rem >> 32)) << 32) |
-                      (unsigned)__builtin_amdgcn_readfirstlane((unsigned)rem);
-                // one step per KEPT row (s_ff1 on the rows still alive), not per row: a dense scene keeps a few of 64
-                unsigned long long keepbits = 0ull;
-                carry = 0ull;
-                while (~rem != 0ull) {
-                    const int r = __builtin_ctzll(~rem);
-                    keepbits |= 1ull << r;
-                    rem |= (1ull << r) | ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, r) << 32) |
-                           (unsigned)__builtin_amdgcn_readlane(dlo, r);
-                    carry |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ahi, r) << 32) |
-                             (unsigned)__builtin_amdgcn_readlane(alo, r);
-                }
-                if (mine) keep[row] = (unsigned char)((keepbits >> lane) & 1ull);
-                if (lane == 0) kept_sh[b & 1] = keepbits;
-            } else if (b >= 1) {
-                // OR stage for block b - 1 (its kept rows were published before the last barrier): words b + 1 ... b_last
-                const unsigned long long keepbits = kept_sh[(b - 1) & 1];
-                const int64_t row0 = (base + b - 1) * 64;
-                const int ntasks = (b_last - b) * 4;   // (word, group of 16 rows)
-                for (int t = threadIdx.x - 64; t < ntasks; t += kSweepBlock - 64) {
-                    const int w = b + 1 + (t >> 2), r0 = (t & 3) * 16;
-                    const unsigned bits = (unsigned)(keepbits >> r0) & 0xffffu;
-                    if (bits == 0u) continue;
-                    const unsigned long long* col = mask + (row0 + r0) * words + w;
-                    unsigned long long v[16];
+        for (int b0 = 0; b0 <= b_last; b0 += 3) {
 #pragma unroll
-                    for (int u = 0; u < 16; u++) v[u] = ((bits >> u) & 1u) ? col[(int64_t)u * words] : 0ull;
-                    unsigned long long acc = 0ull;
+            for (int u = 0; u < 3; u++) {
+                const int b = b0 + u;
+                if (b > b_last) break;   // workgroup-uniform
+                if (wave == 0) {
+                    const int64_t row = (base + b) * 64 + lane;
+                    const bool mine = row >= s && row < seg_end;
+                    const unsigned dlo = (unsigned)dg[u], dhi = (unsigned)(dg[u] >> 32);
+                    const unsigned alo = (unsigned)af[u], ahi = (unsigned)(af[u] >> 32);
+                    // scalar (SGPR) state of the serial chain; rows of the block outside this segment start out "removed"
+                    // (the readlane builtins return int: cast before widening, or bit 31 sign-extends)
+                    unsigned long long rem = removed[b] | carry | ~__builtin_amdgcn_ballot_w64(mine);
+                    rem = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(rem >> 32)) << 32) |
+                          (unsigned)__builtin_amdgcn_readfirstlane((unsigned)rem);
+                    // one step per KEPT row (s_ff1 on the rows still alive), not per row: a dense scene keeps a few of 64
+                    unsigned long long keepbits = 0ull;
+                    carry = 0ull;
+                    while (~rem != 0ull) {
+                        const int r = __builtin_ctzll(~rem);
+                        keepbits |= 1ull << r;
+                        rem |= (1ull << r) | ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, r) << 32) |
+                               (unsigned)__builtin_amdgcn_readlane(dlo, r);
+                        carry |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ahi, r) << 32) |
+                                 (unsigned)__builtin_amdgcn_readlane(alo, r);
+                    }
+                    dg[(u + 2) % 3] = load_word(b + 2, b + 2);   // this set held block b - 1: consumed
+                    af[(u + 2) % 3] = load_word(b + 2, b + 3);
+                    if (mine) keep[row] = (unsigned char)((keepbits >> lane) & 1ull);
+                    if (lane == 0) kept_sh[b & 1] = keepbits;
+                } else if (b >= 1) {
+                    // OR stage for block b - 1 (its kept rows were published before the last barrier): words b + 1 ... b_last
+                    const unsigned long long keepbits = kept_sh[(b - 1) & 1];
+                    const int64_t row0 = (base + b - 1) * 64;
+                    const int ntasks = (b_last - b) * 4;   // (word, group of 16 rows)
+                    for (int t = threadIdx.x - 64; t < ntasks; t += kSweepBlock - 64) {
+                        const int w = b + 1 + (t >> 2), r0 = (t & 3) * 16;
+                        const unsigned bits = (unsigned)(keepbits >> r0) & 0xffffu;
+                        if (bits == 0u) continue;
+                        const unsigned long long* col = mask + (row0 + r0) * words + w;
+                        unsigned long long v[16];
 #pragma unroll
-                    for (int u = 0; u < 16; u++) acc |= v[u];
-                    if (acc) atomicOr(&removed[w], acc);
+                        for (int q = 0; q < 16; q++) v[q] = ((bits >> q) & 1u) ? col[(int64_t)q * words] : 0ull;
+                        unsigned long long acc = 0ull;
+#pragma unroll
+                        for (int q = 0; q < 16; q++) acc |= v[q];
+                        if (acc) atomicOr(&removed[w], acc);
+                    }
                 }
+                // LDS-only barrier: the waves talk through removed[] and kept_sh[] alone (the workers have consumed their loads
+                // before their ds_or; nobody reads keep[]), and wave 0's prefetch must stay in flight across it
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
-            __syncthreads();
         }
+        __syncthreads();
     }
 }
 
