@@ -184,6 +184,11 @@ __global__ __launch_bounds__(kBlock) void nms_mask_compact_kernel(const float* _
 // serial chain's prefetch is 8 cache lines per block instead of 128 (148 us, r07g_diag.log).  What IS known: one class of 1 000 /
 // 2 500 / 5 000 / 10 000 / 20 000 boxes sweeps in 16.5 / 40.3 / 79.2 / 184 / 523 us — ~1 us per 64 rows up to 5 000 boxes
 // whatever the block size, the workgroup's size or the layout of the words the chain reads; VALU issue 0.6 % (r07b PMC).)
+// (And with the OR stage two blocks deep ON TOP of the prefetch fix below — wave 0 carrying two words per row, the workers' loads
+// issued in one iteration and consumed in the next across the LDS-only barrier, static register sets: bit-equal, 146.1 -> 143.5 us
+// for one class of 5 000, 38.1 -> 42.1 us for 37 classes (r07i_sweep2.log).  Not kept: what a block costs is wave 0's own
+// instruction chain — a lone wave issues a dependent instruction every ~9 cycles, 14 per kept row, ~7 kept rows per block, plus
+// the LDS read, the ballot, the store and the barrier.)
 constexpr int kSweepBlock = 512, kSweepCands = 4;
 __global__ __launch_bounds__(kSweepBlock) void nms_sweep_kernel(const unsigned long long* __restrict__ mask,
                                                                 const int64_t* __restrict__ cls, int64_t k, int words,
